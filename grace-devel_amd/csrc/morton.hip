@@ -1,0 +1,218 @@
+// Morton keys and centroid bounds for gfx950.
+//
+// Replaces morton_keys_kernel (reference include/grace/cuda/kernels/morton.cuh:30-55), the
+// host scale computation (morton.cuh:97-119) and, for the bounds-free overloads, the
+// compute_centroids kernel + two thrust::reduce passes (morton.cuh:139-174,
+// kernels/aabb.cuh:14-48) -- here one fused streaming pass.
+//
+// HBM-bound streaming work: one float4 (16 B) coalesced load per lane, one 4/8 B store.
+// Algorithmic bytes: 20 B/sphere (30-bit keys), 24 B/sphere (63-bit); bounds pass 16 B/sphere.
+#include "common.hpp"
+
+using namespace grace_hip;
+
+namespace {
+
+__device__ __forceinline__ uint32_t space_by_two_10bit(uint32_t x)
+{
+    x &= (1u << 10) - 1;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t space_by_two_21bit(uint64_t x)
+{
+    // Magic numbers as in the reference (generic/bits.h:35-46), pinned by its 63-bit
+    // known-answer test.
+    x &= (1u << 21) - 1;
+    x = (x | x << 32) & 0x001f00000000ffffull;
+    x = (x | x << 16) & 0x001f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+template <typename Key>
+struct Interleave;
+
+template <>
+struct Interleave<uint32_t> {
+    static __device__ __forceinline__ uint32_t key(uint32_t x, uint32_t y, uint32_t z)
+    {
+        return space_by_two_10bit(z) << 2 | space_by_two_10bit(y) << 1 | space_by_two_10bit(x);
+    }
+};
+
+template <>
+struct Interleave<uint64_t> {
+    static __device__ __forceinline__ uint64_t key(uint64_t x, uint64_t y, uint64_t z)
+    {
+        return space_by_two_21bit(z) << 2 | space_by_two_21bit(y) << 1 | space_by_two_21bit(x);
+    }
+};
+
+// Real is the precision of the bounds (Real3 in the reference): scale * (centre - min) is
+// evaluated in Real, the float centre being promoted when Real = double.
+template <typename Key, typename Real>
+__global__ __launch_bounds__(256) void morton_keys_kernel(const float4* __restrict__ spheres,
+                                                          size_t n, Real minx, Real miny,
+                                                          Real minz, Real sx, Real sy, Real sz,
+                                                          Key* __restrict__ keys)
+{
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x) {
+        const float4 s = spheres[i];
+        const Key x = static_cast<Key>(sx * (s.x - minx));
+        const Key y = static_cast<Key>(sy * (s.y - miny));
+        const Key z = static_cast<Key>(sz * (s.z - minz));
+        keys[i] = Interleave<Key>::key(x, y, z);
+    }
+}
+
+// Order-preserving float <-> uint map so that min/max can use integer atomics.
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__host__ inline float ord2f(uint32_t u)
+{
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+__global__ __launch_bounds__(256) void minmax_f4_kernel(const float4* __restrict__ v, size_t n,
+                                                        uint32_t* __restrict__ out8)
+{
+    float lo[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
+    float hi[4] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x) {
+        const float4 s = v[i];
+        const float c[4] = { s.x, s.y, s.z, s.w };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = fminf(lo[k], c[k]);
+            hi[k] = fmaxf(hi[k], c[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+    __shared__ float s_lo[4][4], s_hi[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s_lo[wave][k] = lo[k];
+            s_hi[wave][k] = hi[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        float l = s_lo[0][k], h = s_hi[0][k];
+        for (int w = 1; w < 4; ++w) {
+            l = fminf(l, s_lo[w][k]);
+            h = fmaxf(h, s_hi[w][k]);
+        }
+        atomicMin(&out8[k], f2ord(l));
+        atomicMax(&out8[4 + k], f2ord(h));
+    }
+}
+
+grace_status minmax_f4(const float* d_v4, size_t n, float* h_mins4, float* h_maxs4,
+                       hipStream_t stream)
+{
+    GRACE_REQUIRE(d_v4 && n > 0, "minmax: empty input");
+    GRACE_TRY(Workspace::begin(256));
+    uint32_t* d_out = Workspace::take<uint32_t>(8);
+    GRACE_TRY_HIP(hipMemsetAsync(d_out, 0xFF, 16, stream));
+    GRACE_TRY_HIP(hipMemsetAsync(d_out + 4, 0x00, 16, stream));
+    minmax_f4_kernel<<<stream_grid(n, 256, 4), 256, 0, stream>>>(
+        reinterpret_cast<const float4*>(d_v4), n, d_out);
+    GRACE_CHECK_LAUNCH();
+    uint32_t h[8];
+    GRACE_TRY_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, stream));
+    GRACE_TRY_HIP(hipStreamSynchronize(stream));
+    for (int k = 0; k < 4; ++k) {
+        h_mins4[k] = ord2f(h[k]);
+        h_maxs4[k] = ord2f(h[4 + k]);
+    }
+    return GRACE_OK;
+}
+
+template <typename Key, typename Real>
+grace_status morton_keys(const float* d_spheres, size_t n, const Real* bot, const Real* top,
+                         Key* d_keys, hipStream_t stream)
+{
+    GRACE_REQUIRE(d_spheres && d_keys && bot && top, "morton_keys: null pointer");
+    if (n == 0) return GRACE_OK;
+    // Host-side scale in Real3 precision, integer span (morton.cuh:104-113).
+    const int span = sizeof(Key) > 4 ? (1u << 21) - 1 : (1u << 10) - 1;
+    const Real sx = span / (top[0] - bot[0]);
+    const Real sy = span / (top[1] - bot[1]);
+    const Real sz = span / (top[2] - bot[2]);
+    morton_keys_kernel<Key, Real><<<stream_grid(n, 256), 256, 0, stream>>>(
+        reinterpret_cast<const float4*>(d_spheres), n, bot[0], bot[1], bot[2], sx, sy, sz,
+        d_keys);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+grace_status grace_minmax_f4(const float* d_v4, size_t n, float* h_mins4, float* h_maxs4,
+                             grace_stream stream)
+{
+    GRACE_REQUIRE(h_mins4 && h_maxs4, "minmax: null output");
+    return minmax_f4(d_v4, n, h_mins4, h_maxs4, as_stream(stream));
+}
+
+grace_status grace_centroid_bounds_f4(const float* d_spheres, size_t n, float* h_bot,
+                                      float* h_top, grace_stream stream)
+{
+    GRACE_REQUIRE(h_bot && h_top, "centroid_bounds: null output");
+    float lo[4], hi[4];
+    GRACE_TRY(minmax_f4(d_spheres, n, lo, hi, as_stream(stream)));
+    for (int k = 0; k < 3; ++k) {
+        h_bot[k] = lo[k];
+        h_top[k] = hi[k];
+    }
+    return GRACE_OK;
+}
+
+grace_status grace_morton_keys30_f4(const float* d_spheres, size_t n, const float* h_bot,
+                                    const float* h_top, uint32_t* d_keys, grace_stream stream)
+{
+    return morton_keys<uint32_t, float>(d_spheres, n, h_bot, h_top, d_keys, as_stream(stream));
+}
+
+grace_status grace_morton_keys63_f4(const float* d_spheres, size_t n, const float* h_bot,
+                                    const float* h_top, uint64_t* d_keys, grace_stream stream)
+{
+    return morton_keys<uint64_t, float>(d_spheres, n, h_bot, h_top, d_keys, as_stream(stream));
+}
+
+grace_status grace_morton_keys63_f4_d3(const float* d_spheres, size_t n, const double* h_bot,
+                                       const double* h_top, uint64_t* d_keys,
+                                       grace_stream stream)
+{
+    return morton_keys<uint64_t, double>(d_spheres, n, h_bot, h_top, d_keys, as_stream(stream));
+}
+
+} // extern "C"

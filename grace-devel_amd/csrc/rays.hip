@@ -1,0 +1,191 @@
+// Deterministic ray generators for gfx950 (inputs of the traversal).
+//
+// orthogonal_z : tests/helper/rays.cuh:55-79 (orthogonal_rays_z) ->
+//                orthographic_projection_rays (include/grace/cuda/kernels/gen_rays.cuh:
+//                319-360, 667-725) for the -z view; bit-identical to the reference's
+//                arithmetic for this axis-aligned case (every cross term is exactly zero).
+// healpix      : one source, HEALPix nested pixel centres, the role of
+//                RayVectorGeneration/src/generateRays.c:57-59 (pix2vec_nest).
+// isotropic    : uniform_random_rays (gen_rays.cuh:104-170, 401-490): Gaussian-normalised
+//                directions sorted by ray_dir_morton_key (gen_rays.cuh:38-43).  The
+//                reference's cuRAND XORWOW streams are device-specific by its own account
+//                (gen_rays.cuh:21-24); here a counter-based generator (splitmix64 of
+//                (seed, ray index)) makes the rays reproducible on any device.
+// Streaming kernels: 28 B written per ray.
+#include "common.hpp"
+
+using namespace grace_hip;
+
+namespace {
+
+struct Ray7 { float dx, dy, dz, ox, oy, oz, length; };
+
+__global__ __launch_bounds__(256) void ortho_z_kernel(int n_side, float cam_x, float cam_y,
+                                                      float cam_z, float vx, float uy,
+                                                      float length, float* __restrict__ rays)
+{
+    const int n = n_side * n_side;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int i = t % n_side, j = t / n_side;
+        // image_plane_coord, gen_rays.cuh:76-97 (+0.5 = pixel centres), aspect ratio 1.
+        const float x = (2 * ((i + 0.5f) / n_side) - 1) * 1.0f;
+        const float y = 1 - 2 * ((j + 0.5f) / n_side);
+        float* r = rays + 7 * size_t(t);
+        r[0] = 0.f; r[1] = 0.f; r[2] = -1.f;
+        r[3] = cam_x + x * vx;
+        r[4] = cam_y + y * uy;
+        r[5] = cam_z;
+        r[6] = length;
+    }
+}
+
+// HEALPix nested -> unit vector (Gorski et al. 2005, eqs. for the nested scheme).
+__device__ __forceinline__ void pix2vec_nest(int nside, int ipix, double* v)
+{
+    const int jrll[12] = { 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4 };
+    const int jpll[12] = { 1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7 };
+    const double halfpi = 1.570796326794896619231321691639751442099;
+    const int npface = nside * nside;
+    const long long npix = 12ll * npface;
+    const int face = ipix / npface;
+    const int ipf = ipix % npface;
+    int ix = 0, iy = 0;
+    for (int b = 0; b < 15; ++b) {
+        ix |= ((ipf >> (2 * b)) & 1) << b;
+        iy |= ((ipf >> (2 * b + 1)) & 1) << b;
+    }
+    const int nl4 = 4 * nside;
+    const int jr = jrll[face] * nside - ix - iy - 1;
+    const double fact2 = 4.0 / npix, fact1 = (nside << 1) * fact2;
+    int nr, kshift;
+    double z;
+    if (jr < nside) { nr = jr; z = 1.0 - double(nr) * nr * fact2; kshift = 0; }
+    else if (jr > 3 * nside) { nr = nl4 - jr; z = double(nr) * nr * fact2 - 1.0; kshift = 0; }
+    else { nr = nside; z = (2 * nside - jr) * fact1; kshift = (jr - nside) & 1; }
+    int jp = (jpll[face] * nr + ix - iy + 1 + kshift) / 2;
+    if (jp > nl4) jp -= nl4;
+    if (jp < 1) jp += nl4;
+    const double phi = (jp - (kshift + 1) * 0.5) * (halfpi / nr);
+    const double st = sqrt((1.0 - z) * (1.0 + z));
+    v[0] = st * cos(phi); v[1] = st * sin(phi); v[2] = z;
+}
+
+__global__ __launch_bounds__(256) void healpix_kernel(int nside, float ox, float oy, float oz,
+                                                      float length, float* __restrict__ rays)
+{
+    const int n = 12 * nside * nside;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        double v[3];
+        pix2vec_nest(nside, t, v);
+        float* r = rays + 7 * size_t(t);
+        r[0] = float(v[0]); r[1] = float(v[1]); r[2] = float(v[2]);
+        r[3] = ox; r[4] = oy; r[5] = oz; r[6] = length;
+    }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ float u01(uint32_t bits) // (0, 1]
+{
+    return (float(bits >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ uint32_t space10(uint32_t x)
+{
+    x &= 1023u;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void isotropic_kernel(size_t n, float ox, float oy, float oz,
+                                                        float length, uint64_t seed,
+                                                        float* __restrict__ rays,
+                                                        uint32_t* __restrict__ keys)
+{
+    for (size_t t = blockIdx.x * size_t(blockDim.x) + threadIdx.x; t < n;
+         t += size_t(gridDim.x) * blockDim.x) {
+        const uint64_t a = splitmix64(seed ^ splitmix64(2 * t));
+        const uint64_t b = splitmix64(seed ^ splitmix64(2 * t + 1));
+        // Three standard normals by Box-Muller, then normalise (gen_rays.cuh:127-147).
+        const float r1 = sqrtf(-2.0f * logf(u01(uint32_t(a))));
+        const float r2 = sqrtf(-2.0f * logf(u01(uint32_t(b))));
+        const float t1 = 6.283185307179586f * u01(uint32_t(a >> 32));
+        const float t2 = 6.283185307179586f * u01(uint32_t(b >> 32));
+        float gx = r1 * cosf(t1), gy = r1 * sinf(t1), gz = r2 * cosf(t2);
+        float norm2 = gx * gx + gy * gy + gz * gz;
+        if (!(norm2 > 0.f)) { gx = 1.f; gy = 0.f; gz = 0.f; norm2 = 1.f; }
+        const float inv = 1.0f / sqrtf(norm2);
+        const float dx = gx * inv, dy = gy * inv, dz = gz * inv;
+        float* r = rays + 7 * t;
+        r[0] = dx; r[1] = dy; r[2] = dz; r[3] = ox; r[4] = oy; r[5] = oz; r[6] = length;
+        // ray_dir_morton_key: morton_key((d + 1) / 2) with span 1023 (generic/morton.h:32-42)
+        const uint32_t kx = uint32_t(1023u * ((dx + 1) / 2.f));
+        const uint32_t ky = uint32_t(1023u * ((dy + 1) / 2.f));
+        const uint32_t kz = uint32_t(1023u * ((dz + 1) / 2.f));
+        keys[t] = space10(kz) << 2 | space10(ky) << 1 | space10(kx);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+grace_status grace_rays_orthogonal_z(int n_side, const float* h_mins4, const float* h_maxs4,
+                                     void* d_rays, float* h_area, grace_stream stream)
+{
+    GRACE_REQUIRE(n_side > 0 && h_mins4 && h_maxs4 && d_rays, "orthogonal_rays_z: bad argument");
+    GRACE_REQUIRE(size_t(n_side) * n_side < (size_t(1) << 31), "orthogonal_rays_z: too many rays");
+    // box_center / box_span, tests/helper/rays.cuh:11-29 (float sums, double halving).
+    const float cx = float((h_mins4[0] + h_maxs4[0]) / 2.);
+    const float cy = float((h_mins4[1] + h_maxs4[1]) / 2.);
+    float sx = h_maxs4[0] - h_mins4[0] + 2 * h_maxs4[3];
+    float sy = h_maxs4[1] - h_mins4[1] + 2 * h_maxs4[3];
+    const float sz = h_maxs4[2] - h_mins4[2] + 2 * h_maxs4[3];
+    if (sx > sy) sy = sx; else if (sy > sx) sx = sy;
+    if (h_area) *h_area = (sx / n_side) * (sy / n_side);
+    // v = (1,0,0) * horizontal_extent / 2, u = (0,1,0) * vertical_extent / 2
+    // (gen_rays.cuh:696-706); camera at (cx, cy, span.z), length 2 * span.z.
+    const float vx = float(1.f * (sy / 2.));
+    const float uy = float(1.f * (sy / 2.));
+    const size_t n = size_t(n_side) * n_side;
+    ortho_z_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
+        n_side, cx, cy, sz, vx, uy, 2 * sz, static_cast<float*>(d_rays));
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+grace_status grace_rays_healpix(int nside, float ox, float oy, float oz, float length,
+                                void* d_rays, grace_stream stream)
+{
+    GRACE_REQUIRE(nside >= 1 && nside <= 8192 && (nside & (nside - 1)) == 0 && d_rays,
+                  "healpix: nside must be a power of two in [1, 8192]");
+    const size_t n = 12 * size_t(nside) * nside;
+    healpix_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
+        nside, ox, oy, oz, length, static_cast<float*>(d_rays));
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+grace_status grace_rays_isotropic(size_t n_rays, float ox, float oy, float oz, float length,
+                                  uint64_t seed, void* d_rays, grace_stream stream)
+{
+    GRACE_REQUIRE(n_rays > 0 && d_rays, "isotropic rays: bad argument");
+    hipStream_t st = as_stream(stream);
+    GRACE_TRY(Workspace::begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28)));
+    uint32_t* keys = Workspace::take<uint32_t>(n_rays);
+    isotropic_kernel<<<stream_grid(n_rays, 256), 256, 0, st>>>(
+        n_rays, ox, oy, oz, length, seed, static_cast<float*>(d_rays), keys);
+    GRACE_CHECK_LAUNCH();
+    return sort_pairs_u32_nested(keys, d_rays, n_rays, 28, 0, 30, nullptr, st);
+}
+
+} // extern "C"

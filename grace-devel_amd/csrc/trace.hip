@@ -1,0 +1,388 @@
+// BVH traversal with ray-sphere tests and SPH-kernel line integrals, for gfx950.
+//
+// Replaces trace_kernel (reference include/grace/cuda/kernels/bintree_trace.cuh:52-197) as
+// instantiated by trace_hitcounts_sph / trace_cumulative_sph / trace_sph
+// (include/grace/cuda/trace_sph.cuh:58-168) with the functors of
+// include/grace/cuda/functors/trace.cuh, AABBs_hit (include/grace/cuda/device/intersect.cuh:
+// 10-40) and sphere_hit (include/grace/generic/intersect.h:10-55).
+//
+// Same traversal semantics: a packet of rays shares one stack; a child is pushed if ANY
+// ray of the packet hits its box (right first, so the left subtree is walked first and
+// every ray meets its hits in ascending primitive index); every ray of the packet is
+// tested against every sphere of every leaf the packet enters.  Results per ray therefore
+// equal the brute-force loop over all spheres (the reference's own criterion,
+// tests/tree_traversal/tree_traversal.cu:65-100) and the fp32 sums are formed in the same
+// order.
+//
+// CDNA4 design (not the reference's):
+//   * packet = one 64-lane wavefront (the reference: a 32-thread warp);
+//   * the packet's stack lives in TWO VGPRs indexed by lane (pop = v_readlane, push =
+//     lane-select, with a scalar stack pointer): 128 entries, no LDS traffic, no bank conflicts;
+//   * every BVH node, leaf record and sphere is wave-uniform, so it is fetched by the
+//     SCALAR unit (s_load_dwordx4/x16 through the scalar data cache) and the box / sphere
+//     tests run on the VALU with SGPR operands: no per-lane address VGPRs, no texture
+//     path, no LDS staging of leaf spheres (reference: 4 tex1Dfetch + a shared-memory tile);
+//   * the "any lane hit" votes are the SGPR-pair results of v_cmp (free ballots);
+//   * the 51-entry fp64 kernel-integral table is expanded to (y0, y1 - y0) pairs in LDS:
+//     one ds_read_b128 per hit, and the fp64 FMA of the reference's lerp.
+//   * no FMA contraction anywhere (-ffp-contract=off), IEEE 1/x and sqrt: the reference's
+//     CPU/GPU equality test is built with -fmad=false (tests/tree_traversal/Makefile:5-8).
+//
+// Roofline: divergent tree walk, integer/fp32 scalar-operand work -- no MFMA.  Algorithmic
+// bytes per ray: 28 + 64 * nodes + 16 * leaves + 16 * spheres tested + 4,
+// counted per ray by the `stats` instantiation below.
+#include "common.hpp"
+
+using namespace grace_hip;
+
+namespace {
+
+constexpr int TRACE_BLOCK = 256;
+constexpr int N_TABLE = 51;
+
+// include/grace/cuda/trace_sph.cuh:32-48
+__constant__ double c_kernel_table[N_TABLE] = {
+    1.90986019771937, 1.90563449910964, 1.89304415940934, 1.87230928086763,
+    1.84374947679902, 1.80776276033034, 1.76481079856299, 1.71540816859939,
+    1.66011373131439, 1.59952322363667, 1.53426266082279, 1.46498233888091,
+    1.39235130929287, 1.31705223652377, 1.23977618317103, 1.16121278415369,
+    1.08201943664419, 1.00288866679720, 0.924475767210246, 0.847415371038733,
+    0.772316688105931, 0.699736940377312, 0.630211918937167, 0.564194562399538,
+    0.502076205853037, 0.444144023534733, 0.390518196140658, 0.341148855945766,
+    0.295941946237307, 0.254782896476983, 0.217538645099225, 0.184059547649710,
+    0.154181189781890, 0.127726122453554, 0.104505535066266,
+    8.432088120445191E-002, 6.696547102921641E-002, 5.222604427168923E-002,
+    3.988433820097490E-002, 2.971866601747601E-002, 2.150552303075515E-002,
+    1.502124104014533E-002, 1.004371608622562E-002, 6.354242122978656E-003,
+    3.739494884706115E-003, 1.993729589156428E-003, 9.212900163813992E-004,
+    3.395908945333921E-004, 8.287326418242995E-005, 7.387919939044624E-006,
+    0.000000000000000E+000
+};
+
+enum { MODE_COUNT = 0, MODE_CUMULATIVE = 1, MODE_HITS = 2, MODE_STATS = 3 };
+
+struct TraceArgs {
+    const float* rays;      // 7 floats per ray
+    int n_rays;
+    const float4* spheres;
+    const float4* nodes;    // 4 x float4 per node
+    int n_nodes;
+    const int4* leaves;
+    const int* root;
+    int* out_counts;        // MODE_COUNT
+    float* out_sums;        // MODE_CUMULATIVE
+    const int* offsets;     // MODE_HITS
+    int* hit_idx;
+    float* hit_integral;
+    float* hit_dist;
+    uint32_t* stats;        // MODE_STATS, 4 per ray
+    int* status;            // set to GRACE_STACK_OVERFLOW on stack exhaustion
+};
+
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+// Integer min/max on float bit patterns, as the reference's vmin/vmax PTX
+// (include/grace/cuda/device/intrinsics.cuh:8-51).
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// include/grace/cuda/device/intersect.cuh:10-40.  Box corners are wave-uniform (SGPRs).
+__device__ __forceinline__ int aabbs_hit(const float ix, const float iy, const float iz,
+                                         const float ox, const float oy, const float oz,
+                                         const float len, const float4 L, const float4 R,
+                                         const float4 Z)
+{
+    const float bx_L = (L.x - ox) * ix, tx_L = (L.y - ox) * ix;
+    const float by_L = (L.z - oy) * iy, ty_L = (L.w - oy) * iy;
+    const float bz_L = (Z.x - oz) * iz, tz_L = (Z.y - oz) * iz;
+    const float bx_R = (R.x - ox) * ix, tx_R = (R.y - ox) * ix;
+    const float by_R = (R.z - oy) * iy, ty_R = (R.w - oy) * iy;
+    const float bz_R = (Z.z - oz) * iz, tz_R = (Z.w - oz) * iz;
+
+    const int zero = __float_as_int(0.0f), ilen = __float_as_int(len);
+    const int tmin_L = imax(imax(__float_as_int(fminf(bx_L, tx_L)), __float_as_int(fminf(by_L, ty_L))),
+                            imax(imin(__float_as_int(bz_L), __float_as_int(tz_L)), zero));
+    const int tmax_L = imin(imin(__float_as_int(fmaxf(bx_L, tx_L)), __float_as_int(fmaxf(by_L, ty_L))),
+                            imin(imax(__float_as_int(bz_L), __float_as_int(tz_L)), ilen));
+    const int tmin_R = imax(imax(__float_as_int(fminf(bx_R, tx_R)), __float_as_int(fminf(by_R, ty_R))),
+                            imax(imin(__float_as_int(bz_R), __float_as_int(tz_R)), zero));
+    const int tmax_R = imin(imin(__float_as_int(fmaxf(bx_R, tx_R)), __float_as_int(fmaxf(by_R, ty_R))),
+                            imin(imax(__float_as_int(bz_R), __float_as_int(tz_R)), ilen));
+    return int(__int_as_float(tmax_R) >= __int_as_float(tmin_R))
+         + 2 * int(__int_as_float(tmax_L) >= __int_as_float(tmin_L));
+}
+
+// OnHit_sphere_cumulate / _individual arithmetic (functors/trace.cuh:181-186) with lerp
+// (include/grace/generic/interpolate.h:11-39, device branch).  lut[i] = (y_i, y_{i+1} - y_i).
+__device__ __forceinline__ float hit_integral(const float b2, const float h, const double2* lut)
+{
+    const float ir = 1.f / h;
+    float b = (N_TABLE - 1) * (__builtin_sqrtf(b2) * ir);
+    int x_idx = static_cast<int>(b);
+    if (x_idx >= N_TABLE - 1) {
+        b = static_cast<float>(N_TABLE - 1);
+        x_idx = N_TABLE - 2;
+    }
+    const double2 y = lut[x_idx];
+    const double t = static_cast<double>(b) - x_idx;
+    float integral = static_cast<float>(__builtin_fma(t, y.y, y.x));
+    integral *= (ir * ir);
+    return integral;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
+{
+    __shared__ double2 s_lut[N_TABLE];
+    if (MODE == MODE_CUMULATIVE || MODE == MODE_HITS) {
+        if (threadIdx.x < N_TABLE) {
+            const double y0 = c_kernel_table[threadIdx.x];
+            const double y1 = threadIdx.x + 1 < N_TABLE ? c_kernel_table[threadIdx.x + 1] : y0;
+            s_lut[threadIdx.x] = make_double2(y0, y1 - y0);
+        }
+        __syncthreads();
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int packet = __builtin_amdgcn_readfirstlane(blockIdx.x * (TRACE_BLOCK / 64)
+                                                      + (threadIdx.x >> 6));
+    const int first_ray = packet * 64;
+    if (first_ray >= a.n_rays) return;
+    const int ray_index = first_ray + lane;
+    const bool valid = ray_index < a.n_rays;
+    // Tail lanes re-trace the last ray so that they do not widen the packet.
+    const float* rp = a.rays + 7 * size_t(valid ? ray_index : a.n_rays - 1);
+    const float dx = rp[0], dy = rp[1], dz = rp[2];
+    const float ox = rp[3], oy = rp[4], oz = rp[5];
+    const float len = rp[6];
+    const float ix = 1.f / dx, iy = 1.f / dy, iz = 1.f / dz; // bintree_trace.cuh:111-114
+
+    int count = 0;
+    float sum = 0.f;
+    int write_at = 0;
+    if (MODE == MODE_HITS) write_at = a.offsets[valid ? ray_index : a.n_rays - 1];
+    uint32_t st_nodes = 0, st_leaves = 0, st_tested = 0;
+
+    // Packet stack: entry e lives in lane (e & 63) of stk0 (e < 64) or stk1.
+    int stk0 = 0, stk1 = 0;
+    // MODE_STATS: per entry, the lanes that reach it on their own.
+    int ml0 = 0, mh0 = 0, ml1 = 0, mh1 = 0;
+    int sp = -1;
+    bool overflow = false;
+
+    // v_writelane is not exposed as a builtin by this hipcc; a push is a lane-select
+    // (v_cmp_eq + v_cndmask with the scalar stack pointer), a pop is v_readlane.
+    auto push = [&](const int value, const unsigned long long alive) {
+        if (sp >= 127) { overflow = true; return; }
+        ++sp;
+        if (sp < 64) {
+            const bool me = lane == sp;
+            stk0 = me ? value : stk0;
+            if (MODE == MODE_STATS) {
+                ml0 = me ? int(uint32_t(alive)) : ml0;
+                mh0 = me ? int(uint32_t(alive >> 32)) : mh0;
+            }
+        } else {
+            const bool me = lane == sp - 64;
+            stk1 = me ? value : stk1;
+            if (MODE == MODE_STATS) {
+                ml1 = me ? int(uint32_t(alive)) : ml1;
+                mh1 = me ? int(uint32_t(alive >> 32)) : mh1;
+            }
+        }
+    };
+
+    push(*a.root, ~0ull);
+
+    while (sp >= 0) {
+        int idx;
+        unsigned long long alive_mask = ~0ull;
+        if (sp < 64) {
+            idx = __builtin_amdgcn_readlane(stk0, sp);
+            if (MODE == MODE_STATS)
+                alive_mask = (unsigned long long)uint32_t(__builtin_amdgcn_readlane(ml0, sp))
+                    | ((unsigned long long)uint32_t(__builtin_amdgcn_readlane(mh0, sp)) << 32);
+        } else {
+            idx = __builtin_amdgcn_readlane(stk1, sp - 64);
+            if (MODE == MODE_STATS)
+                alive_mask = (unsigned long long)uint32_t(__builtin_amdgcn_readlane(ml1, sp - 64))
+                    | ((unsigned long long)uint32_t(__builtin_amdgcn_readlane(mh1, sp - 64)) << 32);
+        }
+        --sp;
+        const bool alive = (alive_mask >> lane) & 1ull;
+
+        if (idx < a.n_nodes) {
+            const float4* np = a.nodes + 4 * size_t(idx);
+            const float4 n0 = np[0];
+            const float4 L = np[1];
+            const float4 R = np[2];
+            const float4 Z = np[3];
+            const int lr = aabbs_hit(ix, iy, iz, ox, oy, oz, len, L, R, Z);
+            const bool hit_r = lr & 1, hit_l = lr >= 2;
+            if (MODE == MODE_STATS && alive) ++st_nodes;
+            const unsigned long long vote_r = __builtin_amdgcn_ballot_w64(hit_r);
+            const unsigned long long vote_l = __builtin_amdgcn_ballot_w64(hit_l);
+            if (vote_r) push(__float_as_int(n0.y),
+                             MODE == MODE_STATS ? __builtin_amdgcn_ballot_w64(hit_r && alive) : 0ull);
+            if (vote_l) push(__float_as_int(n0.x),
+                             MODE == MODE_STATS ? __builtin_amdgcn_ballot_w64(hit_l && alive) : 0ull);
+        } else {
+            const int4 leaf = a.leaves[idx - a.n_nodes];
+            if (MODE == MODE_STATS && alive) { ++st_leaves; st_tested += uint32_t(leaf.y); }
+            const float4* sp4 = a.spheres + leaf.x;
+            for (int i = 0; i < leaf.y; ++i) {
+                const float4 s = sp4[i];
+                // sphere_hit, include/grace/generic/intersect.h:16-54
+                const float px = s.x - ox, py = s.y - oy, pz = s.z - oz;
+                const float dot_p = px * dx + py * dy + pz * dz;
+                const float bx = px - dot_p * dx;
+                const float by = py - dot_p * dy;
+                const float bz = pz - dot_p * dz;
+                const float b2 = bx * bx + by * by + bz * bz;
+                const bool hit = !(b2 >= s.w * s.w) && !(dot_p < 0.0f) && !(dot_p >= len);
+                if (MODE == MODE_COUNT || MODE == MODE_STATS) {
+                    count += hit ? 1 : 0;
+                } else if (hit) {
+                    const float w = hit_integral(b2, s.w, s_lut);
+                    if (MODE == MODE_CUMULATIVE) {
+                        sum += w;
+                    } else if (valid) {
+                        a.hit_idx[write_at] = leaf.x + i;
+                        a.hit_integral[write_at] = w;
+                        a.hit_dist[write_at] = dot_p;
+                        ++write_at;
+                    }
+                }
+            }
+        }
+    }
+
+    if (overflow && lane == 0) *a.status = GRACE_STACK_OVERFLOW;
+    if (!valid) return;
+    if (MODE == MODE_COUNT) a.out_counts[ray_index] = count;
+    if (MODE == MODE_CUMULATIVE) a.out_sums[ray_index] = sum;
+    if (MODE == MODE_STATS) {
+        reinterpret_cast<uint4*>(a.stats)[ray_index] =
+            make_uint4(st_nodes, st_leaves, st_tested, uint32_t(count));
+    }
+}
+
+int* g_status = nullptr; // one device int, allocated on first use
+
+grace_status ensure_status(hipStream_t stream)
+{
+    if (!g_status) {
+        GRACE_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&g_status), sizeof(int)));
+        GRACE_TRY_HIP(hipMemsetAsync(g_status, 0, sizeof(int), stream));
+    }
+    return GRACE_OK;
+}
+
+template <int MODE>
+grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n_nodes,
+                          hipStream_t stream)
+{
+    GRACE_REQUIRE(a.rays && a.spheres && a.nodes && a.leaves && a.root, "trace: null pointer");
+    GRACE_REQUIRE(n_rays > 0 && n_rays < (size_t(1) << 31), "trace: bad ray count");
+    GRACE_REQUIRE(n_nodes >= 1 && n_nodes < (size_t(1) << 30), "trace: bad node count");
+    GRACE_REQUIRE(n_spheres > 0, "trace: no primitives");
+    GRACE_TRY(ensure_status(stream));
+    a.n_rays = int(n_rays);
+    a.n_nodes = int(n_nodes);
+    a.status = g_status;
+    const int n_packets = ceil_div(n_rays, 64);
+    trace_kernel<MODE><<<ceil_div(n_packets, TRACE_BLOCK / 64), TRACE_BLOCK, 0, stream>>>(a);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+grace_status grace_trace_hitcounts_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                      size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                      const int* d_leaves, const int* d_root,
+                                      int* d_hit_counts, grace_stream stream)
+{
+    GRACE_REQUIRE(d_hit_counts, "trace_hitcounts: null output");
+    TraceArgs a = {};
+    a.rays = static_cast<const float*>(d_rays);
+    a.spheres = reinterpret_cast<const float4*>(d_spheres);
+    a.nodes = reinterpret_cast<const float4*>(d_nodes);
+    a.leaves = reinterpret_cast<const int4*>(d_leaves);
+    a.root = d_root;
+    a.out_counts = d_hit_counts;
+    return launch_trace<MODE_COUNT>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_trace_cumulative_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                       size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                       const int* d_leaves, const int* d_root,
+                                       float* d_cumulated, grace_stream stream)
+{
+    GRACE_REQUIRE(d_cumulated, "trace_cumulative: null output");
+    TraceArgs a = {};
+    a.rays = static_cast<const float*>(d_rays);
+    a.spheres = reinterpret_cast<const float4*>(d_spheres);
+    a.nodes = reinterpret_cast<const float4*>(d_nodes);
+    a.leaves = reinterpret_cast<const int4*>(d_leaves);
+    a.root = d_root;
+    a.out_sums = d_cumulated;
+    return launch_trace<MODE_CUMULATIVE>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_trace_hits_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                 size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                 const int* d_leaves, const int* d_root,
+                                 const int* d_ray_offsets, int* d_hit_indices,
+                                 float* d_hit_integrals, float* d_hit_distances,
+                                 grace_stream stream)
+{
+    GRACE_REQUIRE(d_ray_offsets && d_hit_indices && d_hit_integrals && d_hit_distances,
+                  "trace_hits: null output");
+    TraceArgs a = {};
+    a.rays = static_cast<const float*>(d_rays);
+    a.spheres = reinterpret_cast<const float4*>(d_spheres);
+    a.nodes = reinterpret_cast<const float4*>(d_nodes);
+    a.leaves = reinterpret_cast<const int4*>(d_leaves);
+    a.root = d_root;
+    a.offsets = d_ray_offsets;
+    a.hit_idx = d_hit_indices;
+    a.hit_integral = d_hit_integrals;
+    a.hit_dist = d_hit_distances;
+    return launch_trace<MODE_HITS>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_trace_stats_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                  size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                  const int* d_leaves, const int* d_root,
+                                  uint32_t* d_stats4, grace_stream stream)
+{
+    GRACE_REQUIRE(d_stats4, "trace_stats: null output");
+    TraceArgs a = {};
+    a.rays = static_cast<const float*>(d_rays);
+    a.spheres = reinterpret_cast<const float4*>(d_spheres);
+    a.nodes = reinterpret_cast<const float4*>(d_nodes);
+    a.leaves = reinterpret_cast<const int4*>(d_leaves);
+    a.root = d_root;
+    a.stats = d_stats4;
+    return launch_trace<MODE_STATS>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_trace_status(grace_stream stream)
+{
+    if (!g_status) return GRACE_OK;
+    int h = 0;
+    GRACE_TRY_HIP(hipMemcpyAsync(&h, g_status, sizeof(int), hipMemcpyDeviceToHost,
+                                 as_stream(stream)));
+    GRACE_TRY_HIP(hipStreamSynchronize(as_stream(stream)));
+    if (h != 0) {
+        GRACE_TRY_HIP(hipMemsetAsync(g_status, 0, sizeof(int), as_stream(stream)));
+        return set_error(GRACE_STACK_OVERFLOW, __FILE__, __LINE__,
+                         "trace: packet stack (128 entries) exhausted");
+    }
+    return GRACE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,360 @@
+"""Python host-side mirror of the grace:: SPH API over libgrace_hip.so (C ABI, ctypes).
+
+Names, argument meaning and error behaviour follow the reference's user-facing functions
+(include/grace/cuda/build_sph.cuh, trace_sph.cuh, scan.cuh, tests/helper/tree.cuh,
+tests/helper/rays.cuh); torch tensors play the role of thrust::device_vector (device
+memory + streams only -- every computation is a hand-written HIP kernel behind the C ABI).
+There is NO CPU fallback: importing this module without the built library raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgrace_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libgrace_hip.so is not built (%s). Run __graft_entry__.build() or "
+        "`make -C grace-devel_amd`. There is no CPU fallback." % LIB_PATH)
+
+_lib = C.CDLL(LIB_PATH)
+_lib.grace_last_error.restype = C.c_char_p
+_lib.grace_version.restype = C.c_int
+
+GRACE_OK = 0
+GRACE_INVALID_ARGUMENT = 1
+GRACE_HIP_ERROR = 2
+GRACE_OUT_OF_MEMORY = 3
+GRACE_STACK_OVERFLOW = 4
+
+RAY_FLOATS = 7  # include/grace/ray.h:5-10
+N_TABLE = 51    # include/grace/cuda/trace_sph.cuh:22
+
+
+class GraceError(RuntimeError):
+    """A GPU API failure; the reference prints the error and exit()s (error.h:40-56)."""
+
+
+def _check(status):
+    if status == GRACE_OK:
+        return
+    msg = _lib.grace_last_error().decode()
+    if status == GRACE_INVALID_ARGUMENT:
+        raise ValueError(msg)  # std::invalid_argument in the reference
+    if status == GRACE_OUT_OF_MEMORY:
+        raise MemoryError(msg)
+    raise GraceError("status %d: %s" % (status, msg))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def _spheres(t):
+    assert t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 4
+    return t
+
+
+def _rays(t):
+    assert t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == RAY_FLOATS
+    return t
+
+
+def version():
+    return _lib.grace_version()
+
+
+def exported_symbols():
+    """Every entry point include/grace_hip.h declares (checked by the CPU tests)."""
+    return _lib
+
+
+# ---------------------------------------------------------------------------------------
+# Tree container -- include/grace/cuda/nodes.h:14-58
+# ---------------------------------------------------------------------------------------
+class Tree:
+    """nodes: int32 [n_nodes, 16] (4 x int4/float4 per node), leaves: int32 [n_leaves, 4],
+    root_index: device int32[1]; allocated for N leaves then shrunk by the build
+    (nodes.h:48-52, albvh.cuh:842-845)."""
+
+    def __init__(self, n_leaves, max_per_leaf=1, device="cuda"):
+        self.max_per_leaf = int(max_per_leaf)
+        self.nodes = torch.zeros((max(int(n_leaves) - 1, 1), 16), dtype=torch.int32, device=device)
+        self.leaves = torch.zeros((int(n_leaves), 4), dtype=torch.int32, device=device)
+        self.root_index = torch.zeros(1, dtype=torch.int32, device=device)
+
+    @property
+    def n_leaves(self):
+        return self.leaves.shape[0]
+
+    @property
+    def n_nodes(self):
+        return self.leaves.shape[0] - 1
+
+
+# ---------------------------------------------------------------------------------------
+# Build -- include/grace/cuda/build_sph.cuh
+# ---------------------------------------------------------------------------------------
+def centroid_bounds(spheres):
+    bot = (C.c_float * 3)(); top = (C.c_float * 3)()
+    _check(_lib.grace_centroid_bounds_f4(_ptr(_spheres(spheres)), C.c_size_t(len(spheres)),
+                                         bot, top, _stream()))
+    return np.array(bot, np.float32), np.array(top, np.float32)
+
+
+def min_max_vec4(v):
+    """grace::min_vec4 / max_vec4 (util/extrema.cuh) in one pass."""
+    lo = (C.c_float * 4)(); hi = (C.c_float * 4)()
+    _check(_lib.grace_minmax_f4(_ptr(_spheres(v)), C.c_size_t(len(v)), lo, hi, _stream()))
+    return np.array(lo, np.float32), np.array(hi, np.float32)
+
+
+def morton_keys_sph(spheres, keys, bot=None, top=None, double_bounds=False):
+    """build_sph.cuh:19-35.  keys.dtype selects 30-bit (int32 storage of uint32) or 63-bit
+    (int64 storage of uint64) keys."""
+    _spheres(spheres)
+    if bot is None:
+        bot, top = centroid_bounds(spheres)
+    n = C.c_size_t(len(spheres))
+    if keys.dtype == torch.int32:
+        b = (C.c_float * 3)(*[float(x) for x in bot]); t = (C.c_float * 3)(*[float(x) for x in top])
+        _check(_lib.grace_morton_keys30_f4(_ptr(spheres), n, b, t, _ptr(keys), _stream()))
+    elif keys.dtype == torch.int64:
+        if double_bounds:
+            b = (C.c_double * 3)(*[float(x) for x in bot]); t = (C.c_double * 3)(*[float(x) for x in top])
+            _check(_lib.grace_morton_keys63_f4_d3(_ptr(spheres), n, b, t, _ptr(keys), _stream()))
+        else:
+            b = (C.c_float * 3)(*[float(x) for x in bot]); t = (C.c_float * 3)(*[float(x) for x in top])
+            _check(_lib.grace_morton_keys63_f4(_ptr(spheres), n, b, t, _ptr(keys), _stream()))
+    else:
+        raise ValueError("keys must be int32 (30-bit) or int64 (63-bit) storage")
+    return keys
+
+
+def sort_by_key(keys, values=None, begin_bit=0, end_bit=None, want_perm=False):
+    """thrust::sort_by_key contract: stable, ascending, keys and values permuted in place."""
+    n = len(keys)
+    perm = torch.empty(n, dtype=torch.int32, device=keys.device) if want_perm else None
+    vb = 0
+    if values is not None:
+        assert values.is_contiguous() and len(values) == n
+        vb = values.element_size() * (values.numel() // max(n, 1))
+    if keys.dtype == torch.int32:
+        fn, bits = _lib.grace_sort_pairs_u32, 32
+    elif keys.dtype == torch.int64:
+        fn, bits = _lib.grace_sort_pairs_u64, 64
+    else:
+        raise ValueError("keys must be int32/int64 storage of unsigned keys")
+    _check(fn(_ptr(keys), _ptr(values), C.c_size_t(n), C.c_int(vb), C.c_int(begin_bit),
+              C.c_int(bits if end_bit is None else end_bit), _ptr(perm), _stream()))
+    return perm
+
+
+def morton_keys30_sort_sph(spheres, bot=None, top=None):
+    """build_sph.cuh:41-58: keys + stable sort of the spheres by key, in place."""
+    keys = torch.empty(len(spheres), dtype=torch.int32, device=spheres.device)
+    morton_keys_sph(spheres, keys, bot, top)
+    sort_by_key(keys, spheres, 0, 30)
+    return keys
+
+
+def morton_keys63_sort_sph(spheres, bot=None, top=None):
+    """build_sph.cuh:65-82."""
+    keys = torch.empty(len(spheres), dtype=torch.int64, device=spheres.device)
+    morton_keys_sph(spheres, keys, bot, top)
+    sort_by_key(keys, spheres, 0, 63)
+    return keys
+
+
+def euclidean_deltas_sph(spheres, deltas):
+    """build_sph.cuh:87-94; deltas has len(spheres) + 1 entries."""
+    assert len(deltas) == len(spheres) + 1 and deltas.dtype == torch.float32
+    _check(_lib.grace_deltas_euclid_f4(_ptr(_spheres(spheres)), C.c_size_t(len(spheres)),
+                                       _ptr(deltas), _stream()))
+    return deltas
+
+
+def surface_area_deltas_sph(spheres, deltas):
+    """build_sph.cuh:98-105."""
+    assert len(deltas) == len(spheres) + 1 and deltas.dtype == torch.float32
+    _check(_lib.grace_deltas_area_f4(_ptr(_spheres(spheres)), C.c_size_t(len(spheres)),
+                                     _ptr(deltas), _stream()))
+    return deltas
+
+
+def XOR_deltas_sph(keys, deltas):
+    """build_sph.cuh:109-114."""
+    assert len(deltas) == len(keys) + 1 and deltas.dtype == keys.dtype
+    fn = _lib.grace_deltas_xor_u32 if keys.dtype == torch.int32 else _lib.grace_deltas_xor_u64
+    _check(fn(_ptr(keys), C.c_size_t(len(keys)), _ptr(deltas), _stream()))
+    return deltas
+
+
+def ALBVH_sph(spheres, deltas, tree):
+    """build_sph.cuh:118-124 -> build_ALBVH (albvh.cuh:986-1021); shrinks tree.nodes/leaves."""
+    n = len(spheres)
+    assert tree.leaves.shape[0] >= n and len(deltas) == n + 1
+    n_leaves = C.c_size_t(0)
+    if deltas.dtype == torch.float32:
+        fn = _lib.grace_albvh_build_f4
+    elif deltas.dtype == torch.int32:
+        fn = _lib.grace_albvh_build_f4_u32
+    else:
+        raise ValueError("deltas must be float32 or 32-bit XOR deltas")
+    _check(fn(_ptr(_spheres(spheres)), C.c_size_t(n), _ptr(deltas), C.c_int(tree.max_per_leaf),
+              _ptr(tree.nodes), _ptr(tree.leaves), _ptr(tree.root_index), C.byref(n_leaves),
+              _stream()))
+    tree.leaves = tree.leaves[: n_leaves.value]
+    tree.nodes = tree.nodes[: n_leaves.value - 1]
+    return tree
+
+
+def build_tree(spheres, tree, low=None, high=None):
+    """tests/helper/tree.cuh:15-43: 30-bit keys, Euclidean deltas, sorts spheres in place."""
+    deltas = torch.empty(len(spheres) + 1, dtype=torch.float32, device=spheres.device)
+    morton_keys30_sort_sph(spheres, low, high)
+    euclidean_deltas_sph(spheres, deltas)
+    ALBVH_sph(spheres, deltas, tree)
+    return tree
+
+
+# ---------------------------------------------------------------------------------------
+# Trace -- include/grace/cuda/trace_sph.cuh
+# ---------------------------------------------------------------------------------------
+def _check_rays(rays):
+    _rays(rays)
+    if len(rays) % 32 != 0:
+        # include/grace/cuda/kernels/bintree_trace.cuh:231-238
+        raise ValueError("Number of rays must be a multiple of the warp size (32).")
+
+
+def _trace_args(rays, spheres, tree):
+    return (_ptr(rays), C.c_size_t(len(rays)), _ptr(_spheres(spheres)), C.c_size_t(len(spheres)),
+            _ptr(tree.nodes), C.c_size_t(tree.n_nodes), _ptr(tree.leaves), _ptr(tree.root_index))
+
+
+def trace_status():
+    _check(_lib.grace_trace_status(_stream()))
+
+
+def trace_hitcounts_sph(rays, spheres, tree, hit_counts):
+    """trace_sph.cuh:58-80."""
+    _check_rays(rays)
+    assert hit_counts.dtype == torch.int32 and len(hit_counts) == len(rays)
+    _check(_lib.grace_trace_hitcounts_f4(*_trace_args(rays, spheres, tree), _ptr(hit_counts),
+                                         _stream()))
+    return hit_counts
+
+
+def trace_cumulative_sph(rays, spheres, tree, cumulated):
+    """trace_sph.cuh:82-110."""
+    _check_rays(rays)
+    assert cumulated.dtype == torch.float32 and len(cumulated) == len(rays)
+    _check(_lib.grace_trace_cumulative_f4(*_trace_args(rays, spheres, tree), _ptr(cumulated),
+                                          _stream()))
+    return cumulated
+
+
+def trace_sph(rays, spheres, tree):
+    """trace_sph.cuh:112-168: returns (ray_offsets, hit_indices, hit_integrals,
+    hit_distances); the reference resizes the three per-hit vectors to the total."""
+    _check_rays(rays)
+    n = len(rays)
+    offsets = torch.empty(n, dtype=torch.int32, device=rays.device)
+    trace_hitcounts_sph(rays, spheres, tree, offsets)
+    total = exclusive_scan(offsets, offsets)
+    idx = torch.empty(total, dtype=torch.int32, device=rays.device)
+    integrals = torch.empty(total, dtype=torch.float32, device=rays.device)
+    dists = torch.empty(total, dtype=torch.float32, device=rays.device)
+    _check(_lib.grace_trace_hits_f4(*_trace_args(rays, spheres, tree), _ptr(offsets), _ptr(idx),
+                                    _ptr(integrals), _ptr(dists), _stream()))
+    return offsets, idx, integrals, dists
+
+
+def trace_stats(rays, spheres, tree):
+    """Per ray {nodes, leaves, spheres tested, hits} for that ray alone."""
+    stats = torch.empty((len(rays), 4), dtype=torch.int32, device=rays.device)
+    _check(_lib.grace_trace_stats_f4(*_trace_args(rays, spheres, tree), _ptr(stats), _stream()))
+    return stats
+
+
+# ---------------------------------------------------------------------------------------
+# Scans -- include/grace/cuda/scan.cuh
+# ---------------------------------------------------------------------------------------
+def exclusive_scan(inp, out):
+    total = C.c_longlong(0)
+    _check(_lib.grace_scan_exclusive_i32(_ptr(inp), C.c_size_t(len(inp)), _ptr(out),
+                                         C.byref(total), _stream()))
+    return total.value
+
+
+def exclusive_segmented_scan(segment_offsets, data, results):
+    """scan.cuh:15-37; data and results may be the same tensor."""
+    assert segment_offsets.dtype == torch.int32 and data.dtype == results.dtype
+    fn = {torch.float32: _lib.grace_segscan_exclusive_f32,
+          torch.float64: _lib.grace_segscan_exclusive_f64}[data.dtype]
+    _check(fn(_ptr(segment_offsets), C.c_size_t(len(segment_offsets)), _ptr(data),
+              C.c_size_t(len(data)), _ptr(results), _stream()))
+    return results
+
+
+def weighted_exclusive_segmented_scan(to_sum, weights, weight_map, segment_offsets, out):
+    """scan.cuh:43-58."""
+    weighted = torch.empty_like(to_sum)
+    _check(_lib.grace_multiply_by_weights_f32(_ptr(to_sum), C.c_size_t(len(to_sum)),
+                                              _ptr(weights), _ptr(weight_map), _ptr(weighted),
+                                              _stream()))
+    return exclusive_segmented_scan(segment_offsets, weighted, out)
+
+
+# ---------------------------------------------------------------------------------------
+# Rays -- tests/helper/rays.cuh, include/grace/cuda/gen_rays.cuh
+# ---------------------------------------------------------------------------------------
+def orthogonal_rays_z(n_side, mins4, maxs4, device="cuda"):
+    """tests/helper/rays.cuh:55-79; returns (rays [n_side^2, 7], area per ray)."""
+    rays = torch.empty((n_side * n_side, RAY_FLOATS), dtype=torch.float32, device=device)
+    lo = (C.c_float * 4)(*[float(x) for x in mins4]); hi = (C.c_float * 4)(*[float(x) for x in maxs4])
+    area = C.c_float(0)
+    _check(_lib.grace_rays_orthogonal_z(C.c_int(n_side), lo, hi, _ptr(rays), C.byref(area),
+                                        _stream()))
+    return rays, area.value
+
+
+def healpix_rays(nside, origin, length, device="cuda"):
+    rays = torch.empty((12 * nside * nside, RAY_FLOATS), dtype=torch.float32, device=device)
+    _check(_lib.grace_rays_healpix(C.c_int(nside), C.c_float(origin[0]), C.c_float(origin[1]),
+                                   C.c_float(origin[2]), C.c_float(length), _ptr(rays), _stream()))
+    return rays
+
+
+def uniform_random_rays(n_rays, origin, length, seed=1234, device="cuda"):
+    """gen_rays.cuh uniform_random_rays: isotropic directions, direction-Morton sorted."""
+    rays = torch.empty((n_rays, RAY_FLOATS), dtype=torch.float32, device=device)
+    _check(_lib.grace_rays_isotropic(C.c_size_t(n_rays), C.c_float(origin[0]),
+                                     C.c_float(origin[1]), C.c_float(origin[2]),
+                                     C.c_float(length), C.c_uint64(seed), _ptr(rays), _stream()))
+    return rays
+
+
+def project_sph(spheres, n_side, max_per_leaf=32):
+    """The projection of tests/project_gadget/project_gadget.cu:58-81: bounds with
+    w = 0, build_tree, orthogonal_rays_z, trace_cumulative_sph.  Sorts spheres in place.
+    Returns (image [n_side, n_side] float32, tree, rays)."""
+    lo, hi = min_max_vec4(spheres)
+    lo[3] = 0.0; hi[3] = 0.0
+    tree = Tree(len(spheres), max_per_leaf, device=spheres.device)
+    build_tree(spheres, tree, lo[:3], hi[:3])
+    rays, _ = orthogonal_rays_z(n_side, lo, hi, device=spheres.device)
+    out = torch.empty(len(rays), dtype=torch.float32, device=spheres.device)
+    trace_cumulative_sph(rays, spheres, tree, out)
+    return out.view(n_side, n_side), tree, rays

@@ -1,0 +1,192 @@
+/*
+ * grace_hip.h -- C ABI of libgrace_hip.so: the MI355X (gfx950) implementation of the
+ * GRACE BVH-build + SPH ray-traversal hot path.
+ *
+ * The reference (spthm/grace-devel) has no FFI layer: its boundary is the header-template
+ * API of namespace grace, compiled by nvcc into the caller.  Each entry point below is one
+ * concrete instantiation of that API over raw device pointers; the reference interface it
+ * replaces is cited as file:line (paths relative to the reference root).  The C++ header
+ * mirror (include/grace/grace.h) forwards to these and restores the reference's error
+ * behaviour (throw std::invalid_argument / print + exit).
+ *
+ * Conventions
+ *  - All pointers named d_* are device pointers on the current HIP device; h_* are host.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *    asynchronous on that stream unless they return a value to the host (documented).
+ *  - Every function returns a grace_status; grace_last_error() describes the last failure
+ *    of the calling thread.
+ *  - Temporaries come from a grow-only device workspace owned by the library (the
+ *    reference allocates and frees thrust temporaries inside every call); it is not
+ *    thread-safe, exactly like the reference's global texture references
+ *    (include/grace/cuda/kernels/bintree_trace.cuh:37-38).
+ *  - float4 / int4 / Ray arrays are passed as float* / int* / void* with the reference's
+ *    memory layout: sphere = {x, y, z, h}; Ray = {dx,dy,dz,ox,oy,oz,length} (28 B,
+ *    include/grace/ray.h:5-10); node = 4 x 16 B, leaf = int4 (include/grace/cuda/nodes.h:22-42).
+ */
+#ifndef GRACE_HIP_H
+#define GRACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum grace_status {
+    GRACE_OK = 0,
+    GRACE_INVALID_ARGUMENT = 1, /* the reference throws std::invalid_argument          */
+    GRACE_HIP_ERROR = 2,        /* the reference prints and exit()s (error.h:40-56)     */
+    GRACE_OUT_OF_MEMORY = 3,
+    GRACE_STACK_OVERFLOW = 4    /* traversal stack exhausted (reference: GRACE_ASSERT)  */
+} grace_status;
+
+typedef void* grace_stream;
+
+int grace_version(void);
+const char* grace_last_error(void);
+
+/* ---- device memory helpers: let HIP-free host code (include/grace) own device vectors,
+ *      the role thrust::device_vector plays in the reference ---------------------------- */
+grace_status grace_device_malloc(void** d_ptr, size_t bytes);
+grace_status grace_device_free(void* d_ptr);
+grace_status grace_memcpy_htod(void* d_dst, const void* h_src, size_t bytes, grace_stream stream);
+grace_status grace_memcpy_dtoh(void* h_dst, const void* d_src, size_t bytes, grace_stream stream);
+grace_status grace_memcpy_dtod(void* d_dst, const void* d_src, size_t bytes, grace_stream stream);
+grace_status grace_memset(void* d_dst, int byte, size_t bytes, grace_stream stream);
+grace_status grace_stream_synchronize(grace_stream stream);
+/* Pre-size / drop the internal workspace (optional). */
+grace_status grace_workspace_reserve(size_t bytes);
+grace_status grace_workspace_release(void);
+
+/* ---- Morton keys ------------------------------------------------------------------- */
+/* AABB of sphere centroids: compute_centroids + min_vec3/max_vec3
+ * (include/grace/cuda/kernels/morton.cuh:153-164), fused into one pass.  Synchronises;
+ * results in host arrays h_bot[3], h_top[3]. */
+grace_status grace_centroid_bounds_f4(const float* d_spheres, size_t n,
+                                      float* h_bot, float* h_top, grace_stream stream);
+/* min_vec4 / max_vec4 over x,y,z,w (include/grace/cuda/util/extrema.cuh, as used by
+ * tests/project_gadget/project_gadget.cu:66-68).  Synchronises. */
+grace_status grace_minmax_f4(const float* d_v4, size_t n, float* h_mins4, float* h_maxs4,
+                             grace_stream stream);
+/* grace::morton_keys(prims, N, bot, top, keys, CentroidSphere) with uinteger32 keys and
+ * Real3 = float3 (include/grace/cuda/kernels/morton.cuh:97-119,30-55; build_sph.cuh:27-35). */
+grace_status grace_morton_keys30_f4(const float* d_spheres, size_t n, const float* h_bot,
+                                    const float* h_top, uint32_t* d_keys, grace_stream stream);
+/* Same with uinteger64 keys (63 bits); float3 and double3 bounds. */
+grace_status grace_morton_keys63_f4(const float* d_spheres, size_t n, const float* h_bot,
+                                    const float* h_top, uint64_t* d_keys, grace_stream stream);
+grace_status grace_morton_keys63_f4_d3(const float* d_spheres, size_t n, const double* h_bot,
+                                       const double* h_top, uint64_t* d_keys,
+                                       grace_stream stream);
+
+/* ---- stable radix sort: the thrust::sort_by_key(keys, values) call sites
+ *      (include/grace/cuda/build_sph.cuh:46,57,70,81; kernels/gen_rays.cuh:483,520,577,615).
+ *      Keys ascending, equal keys keep their input order; values (value_bytes per element,
+ *      a multiple of 4: 4/16/28/32/36 are the reference's payloads) are permuted in place.
+ *      d_values may be NULL (keys only).  d_perm (optional, n uint32) receives the source
+ *      index of every output element. ------------------------------------------------- */
+grace_status grace_sort_pairs_u32(uint32_t* d_keys, void* d_values, size_t n, int value_bytes,
+                                  int begin_bit, int end_bit, uint32_t* d_perm,
+                                  grace_stream stream);
+grace_status grace_sort_pairs_u64(uint64_t* d_keys, void* d_values, size_t n, int value_bytes,
+                                  int begin_bit, int end_bit, uint32_t* d_perm,
+                                  grace_stream stream);
+
+/* ---- deltas: grace::compute_deltas (include/grace/cuda/kernels/albvh.cuh:33-47,949-978)
+ *      with DeltaEuclidean / DeltaSurfaceArea / DeltaXOR
+ *      (include/grace/generic/functors/albvh.h:17-126).  d_deltas has n + 1 entries,
+ *      d_deltas[i] = delta(i - 1); sentinels +inf / all-ones. --------------------------- */
+grace_status grace_deltas_euclid_f4(const float* d_spheres, size_t n, float* d_deltas,
+                                    grace_stream stream);
+grace_status grace_deltas_area_f4(const float* d_spheres, size_t n, float* d_deltas,
+                                  grace_stream stream);
+grace_status grace_deltas_xor_u32(const uint32_t* d_keys, size_t n, uint32_t* d_deltas,
+                                  grace_stream stream);
+grace_status grace_deltas_xor_u64(const uint64_t* d_keys, size_t n, uint64_t* d_deltas,
+                                  grace_stream stream);
+
+/* ---- ALBVH: grace::build_ALBVH (include/grace/cuda/kernels/albvh.cuh:986-1072) with
+ *      DeltaComp = less and AABBSphere.  d_nodes: capacity 16 * (n - 1) ints; d_leaves:
+ *      capacity 4 * n ints; d_root: one device int.  *h_n_leaves receives the leaf count
+ *      (the reference resizes tree.nodes/leaves from it, albvh.cuh:842-845): synchronises.
+ *      GRACE_INVALID_ARGUMENT if n <= max_per_leaf (albvh.cuh:795-799). ---------------- */
+grace_status grace_albvh_build_f4(const float* d_spheres, size_t n, const float* d_deltas,
+                                  int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                  size_t* h_n_leaves, grace_stream stream);
+/* XOR (uint32) deltas variant. */
+grace_status grace_albvh_build_f4_u32(const float* d_spheres, size_t n, const uint32_t* d_deltas,
+                                      int max_per_leaf, int* d_nodes, int* d_leaves,
+                                      int* d_root, size_t* h_n_leaves, grace_stream stream);
+
+/* ---- traversal: grace::trace_hitcounts_sph / trace_cumulative_sph / trace_sph pass 2
+ *      (include/grace/cuda/trace_sph.cuh:58-168) over trace_kernel
+ *      (include/grace/cuda/kernels/bintree_trace.cuh:52-197).  n_nodes = n_leaves - 1.
+ *      Any n_rays >= 1 is accepted here; the header mirror enforces the reference's
+ *      n_rays % 32 == 0 (bintree_trace.cuh:231-238). ---------------------------------- */
+grace_status grace_trace_hitcounts_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                      size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                      const int* d_leaves, const int* d_root,
+                                      int* d_hit_counts, grace_stream stream);
+grace_status grace_trace_cumulative_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                       size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                       const int* d_leaves, const int* d_root,
+                                       float* d_cumulated, grace_stream stream);
+/* Per-hit outputs written from d_ray_offsets[ray] (RayEntry_from_array +
+ * OnHit_sphere_individual, include/grace/cuda/functors/trace.cuh:44-60,196-235). */
+grace_status grace_trace_hits_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                 size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                 const int* d_leaves, const int* d_root,
+                                 const int* d_ray_offsets, int* d_hit_indices,
+                                 float* d_hit_integrals, float* d_hit_distances,
+                                 grace_stream stream);
+/* Instrumented walk: per ray {nodes visited, leaves visited, spheres tested, hits} for that
+ * ray alone (4 x uint32 per ray) -- the counts SURVEY.md section 8d's algorithmic-bytes
+ * formula is built from.  Not part of the reference API. */
+grace_status grace_trace_stats_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                  size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                  const int* d_leaves, const int* d_root,
+                                  uint32_t* d_stats4, grace_stream stream);
+
+/* Reads (and clears) the traversal status word: GRACE_STACK_OVERFLOW if any packet ran out
+ * of its 128-entry stack since the last check (the reference only asserts this in
+ * GRACE_DEBUG builds, bintree_trace.cuh:164).  Synchronises. */
+grace_status grace_trace_status(grace_stream stream);
+
+/* ---- scans ---------------------------------------------------------------------------
+ * thrust::exclusive_scan of hit counts (include/grace/cuda/trace_sph.cuh:135-137).
+ * In place allowed.  *h_total (optional) receives the grand total: synchronises if given. */
+grace_status grace_scan_exclusive_i32(const int* d_in, size_t n, int* d_out, long long* h_total,
+                                      grace_stream stream);
+/* grace::exclusive_segmented_scan (include/grace/cuda/scan.cuh:15-37): per-segment
+ * exclusive prefix sums; segment s covers [offsets[s], offsets[s+1]) (last: to n); empty
+ * segments allowed.  d_data and d_results may alias. */
+grace_status grace_segscan_exclusive_f32(const int* d_segment_offsets, size_t n_segments,
+                                         const float* d_data, size_t n, float* d_results,
+                                         grace_stream stream);
+grace_status grace_segscan_exclusive_f64(const int* d_segment_offsets, size_t n_segments,
+                                         const double* d_data, size_t n, double* d_results,
+                                         grace_stream stream);
+/* detail::multiply_by_weights (include/grace/cuda/kernels/weights.cuh:13-27). */
+grace_status grace_multiply_by_weights_f32(const float* d_unweighted, size_t n,
+                                           const float* d_weights, const uint32_t* d_weight_map,
+                                           float* d_weighted, grace_stream stream);
+
+/* ---- ray inputs (deterministic generators; the reference's cuRAND streams are
+ *      device-specific by its own account, include/grace/cuda/kernels/gen_rays.cuh:21-24) */
+/* orthographic_projection_rays specialised as orthogonal_rays_z
+ * (tests/helper/rays.cuh:55-79; kernels/gen_rays.cuh:319-360,667-725). mins4/maxs4 host. */
+grace_status grace_rays_orthogonal_z(int n_side, const float* h_mins4, const float* h_maxs4,
+                                     void* d_rays, float* h_area, grace_stream stream);
+/* One source, HEALPix nested pixel centres (RayVectorGeneration/src/generateRays.c:57-59). */
+grace_status grace_rays_healpix(int nside, float ox, float oy, float oz, float length,
+                                void* d_rays, grace_stream stream);
+/* Isotropic rays from one origin, sorted by ray_dir_morton_key
+ * (kernels/gen_rays.cuh:38-43,104-170 uniform_random_rays); own counter-based generator. */
+grace_status grace_rays_isotropic(size_t n_rays, float ox, float oy, float oz, float length,
+                                  uint64_t seed, void* d_rays, grace_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRACE_HIP_H */
