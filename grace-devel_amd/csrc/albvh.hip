@@ -31,6 +31,16 @@ using namespace grace_hip;
 
 namespace {
 
+// hipcc (ROCm 7.2) reuses the divergent while-loop's size test after the loop through VCC,
+// whose bits for lanes that left the loop early were zeroed by later iterations (seen in
+// the ISA and as wrong leaves on MI355X).  Re-deriving the size from an opaque VGPR copy
+// forces a fresh compare for every lane.
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // ds is the delta array with the reference's +1 shift: ds[k + 1] = delta(k).
 template <typename D>
 __global__ __launch_bounds__(256) void leaf_heads_kernel(const D* __restrict__ ds, int n, int mpl,
@@ -49,14 +59,14 @@ __global__ __launch_bounds__(256) void leaf_heads_kernel(const D* __restrict__ d
             // separating node is lower in the order: delta(j) < delta(l-1), j < l-1.
             int nl = l - 1;
             while (r - nl + 1 <= mpl && nl >= 1 && ds[nl] < dl) --nl;
-            if (r - nl + 1 > mpl) break;
+            if (opaque(r - nl + 1) > mpl) break;
             l = nl;
         } else {
             // Parent is node r; it owns primitives to the right while the separating
             // node j > r is lower in the order: !(delta(r) < delta(j)).
             int nr = r + 1;
             while (nr - l + 1 <= mpl && nr <= n - 2 && !(dr < ds[nr + 1])) ++nr;
-            if (nr - l + 1 > mpl) break;
+            if (opaque(nr - l + 1) > mpl) break;
             r = nr;
         }
     }
