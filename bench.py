@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the SPH column-density trace (trace_cumulative_sph
+semantics) on the project_gadget workload -- 10^7 particles, 1024^2 orthographic rays
+(BASELINE.json configs[3], the configuration the metric is quoted on; it fits one GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torch.distributed / RCCL when N > 1): every rank builds the same BVH
+from the same seeded particles (the tree is replicated), traces its own contiguous shard of
+the ray grid, and the per-ray integrals are all-gathered over RCCL.  A "step" = one trace of
+the whole ray batch (+ the gather when N > 1) with particles, tree and rays resident in HBM.
+Rank 0 prints ONE JSON line.  The oracle is used only by the cpu_baseline leg (rank 0,
+N = 1) as the thing timed on the host cores, never in the GPU path.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "grace-devel_amd"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_particles(n, device, seed=42):
+    """Synthetic SPH snapshot: n particles uniform in the unit box, smoothing length from
+    the ~48-neighbour rule h = (3*48 / (4 pi n))^(1/3)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    s = torch.empty((n, 4), dtype=torch.float32, device=device)
+    s[:, :3] = torch.rand((n, 3), generator=g, device=device, dtype=torch.float32)
+    s[:, 3] = float((3.0 * 48.0 / (4.0 * math.pi * n)) ** (1.0 / 3.0))
+    return s
+
+
+def cpu_baseline(spheres_host, rays_host, seconds_target=15.0):
+    """The reference's host-side tree_traversal path (OpenMP brute-force sphere_hit over
+    every (ray, sphere) pair, tests/tree_traversal/tree_traversal.cu:65-79) with the
+    column-density accumulation, timed on this box's cores on a bounded ray sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    n_rays = len(rays_host)
+    # Probe, then size the sample for ~seconds_target of work.
+    probe = rays_host[np.linspace(0, n_rays - 1, 4 * cores).astype(np.int64)]
+    t0 = time.perf_counter(); O.brute_cumulative(probe, spheres_host); t1 = time.perf_counter()
+    per_ray = max((t1 - t0) / len(probe), 1e-9)
+    n_sample = int(min(n_rays, max(4 * cores, seconds_target / per_ray)))
+    n_sample = max(cores, (n_sample // cores) * cores)
+    sample = rays_host[np.linspace(0, n_rays - 1, n_sample).astype(np.int64)]
+    t0 = time.perf_counter(); O.brute_cumulative(sample, spheres_host); t1 = time.perf_counter()
+    rate = n_sample / (t1 - t0)
+    return {"value": rate / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d of %d rays (evenly spaced over the image) x %d spheres, brute-force "
+                      "sphere_hit + kernel-integral accumulation, %.1f s wall"
+                      % (n_sample, n_rays, len(spheres_host), t1 - t0),
+            "pair_tests_per_s": rate * len(spheres_host)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles", type=int, default=10_000_000)
+    ap.add_argument("--side", type=int, default=1024)
+    ap.add_argument("--max-per-leaf", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import grace_hip as gh  # raises if libgrace_hip.so is missing: no fallback
+
+    # ---- build (replicated on every rank; timed separately, not part of a step) --------
+    n = args.particles
+    spheres = make_particles(n, device)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    lo, hi = gh.min_max_vec4(spheres)
+    lo[3] = hi[3] = 0.0
+    tree = gh.Tree(n, args.max_per_leaf, device=device)
+    phases = {}
+    keys = torch.empty(n, dtype=torch.int32, device=device)
+    deltas = torch.empty(n + 1, dtype=torch.float32, device=device)
+    e = [ev() for _ in range(5)]
+    e[0].record(); gh.morton_keys_sph(spheres, keys, lo[:3], hi[:3])
+    e[1].record(); gh.sort_by_key(keys, spheres, 0, 30)
+    e[2].record(); gh.euclidean_deltas_sph(spheres, deltas)
+    e[3].record(); gh.ALBVH_sph(spheres, deltas, tree)
+    e[4].record(); torch.cuda.synchronize()
+    for i, name in enumerate(["morton_ms", "sort_ms", "deltas_ms", "albvh_ms"]):
+        phases[name] = round(e[i].elapsed_time(e[i + 1]), 4)
+    del keys, deltas
+
+    # ---- rays: the full grid, then this rank's contiguous shard (multiple of 64) --------
+    rays, area = gh.orthogonal_rays_z(args.side, lo, hi, device=device)
+    n_rays = len(rays)
+    per = ((n_rays + world - 1) // world + 63) // 64 * 64
+    r0 = min(rank * per, n_rays); r1 = min(r0 + per, n_rays)
+    my_rays = rays[r0:r1].contiguous()
+    my_out = torch.zeros(per, dtype=torch.float32, device=device)
+    image = torch.empty(per * world, dtype=torch.float32, device=device) if world > 1 else my_out
+
+    # ---- algorithmic bytes, counted per ray by the instrumented walk ------
+    stats = gh.trace_stats(my_rays, spheres, tree).to(torch.int64).sum(dim=0)
+    if world > 1:
+        dist.all_reduce(stats)
+    nodes_v, leaves_v, tested, hits = [int(x) for x in stats.tolist()]
+    alg_bytes_total = 28 * n_rays + 64 * nodes_v + 16 * leaves_v + 16 * tested + 4 * n_rays
+    gh.trace_status()
+
+    def step():
+        gh.trace_cumulative_sph(my_rays, spheres, tree, my_out[: r1 - r0])
+        if world > 1:
+            dist.all_gather_into_tensor(image, my_out)
+
+    for _ in range(args.warmup):
+        step()
+    kern_ev = [(ev(), ev()) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        kern_ev[k][0].record()
+        gh.trace_cumulative_sph(my_rays, spheres, tree, my_out[: r1 - r0])
+        kern_ev[k][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(image, my_out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in kern_ev) / args.steps
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = float(t[0]), float(t[1])
+    gh.trace_status()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = n_rays * args.steps / elapsed / 1e6
+        # Dominant kernel: trace_kernel<cumulative>.  One launch per rank per step; its
+        # algorithmic bytes are this job's total divided over the ranks.
+        alg_per_launch = alg_bytes_total / world
+        achieved = alg_per_launch / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tfile) and world == 1 and n == 10_000_000 and args.side == 1024:
+            try:
+                traffic = json.load(open(tfile)).get("trace_cumulative_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        img = (image[:n_rays] if world > 1 else my_out[:n_rays])
+        out = {
+            "metric": "Mrays/s SPH column-density trace, 10^7 particles",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "project_gadget: %d uniform-random SPH particles "
+                                   "(h = 48-neighbour rule), %dx%d orthographic -z rays, "
+                                   "max_per_leaf %d" % (n, args.side, args.side,
+                                                        args.max_per_leaf),
+                       "particles": n, "rays": n_rays, "max_per_leaf": args.max_per_leaf,
+                       "sharding": "rays contiguous over %d rank(s), BVH replicated, "
+                                   "all_gather of 4 B/ray" % world},
+            "roofline": {"bound": "hbm", "kernel": "trace_kernel<cumulative>",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": int(alg_per_launch),
+                         "per_ray_mean": {"nodes": nodes_v / n_rays, "leaves": leaves_v / n_rays,
+                                          "spheres_tested": tested / n_rays,
+                                          "hits": hits / n_rays}},
+            "build": dict(phases, n_leaves=tree.n_leaves,
+                          total_ms=round(sum(phases.values()), 4)),
+            "image": {"mean": float(img.mean()), "max": float(img.max())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_s = min(n, len(spheres))
+            out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), rays.cpu().numpy())
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,16 @@
 //     one ds_read_b128 per hit, and the fp64 FMA of the reference's lerp.
 //   * no FMA contraction anywhere (-ffp-contract=off), IEEE 1/x and sqrt: the reference's
 //     CPU/GPU equality test is built with -fmad=false (tests/tree_traversal/Makefile:5-8).
+//   * a streaming pre-pass hoists everything that depends only on the sphere out of the
+//     (ray x sphere) loop: A[i] = {x, y, z, h*h}, B[i] = {1/h, (1/h)^2} -- the same fp32
+//     operations the reference performs per hit, done once per sphere;
+//   * leaf spheres are consumed in chunks of four (one s_load_dwordx16 + one
+//     s_load_dwordx8) with the next chunk's loads issued before the current chunk is
+//     processed; while a leaf is processed the next stack entry's cache line is touched
+//     so that the following pop finds it in the scalar cache;
+//   * packets are dealt to workgroups so that the workgroups sharing an XCD (blockIdx % 8)
+//     walk a contiguous range of packets: neighbouring packets touch the same subtree and
+//     each XCD's 4 MiB L2 keeps it.
 //
 // Roofline: divergent tree walk, integer/fp32 scalar-operand work -- no MFMA.  Algorithmic
 // bytes per ray: 28 + 64 * nodes + 16 * leaves + 16 * spheres tested + 4,
@@ -63,8 +73,11 @@ enum { MODE_COUNT = 0, MODE_CUMULATIVE = 1, MODE_HITS = 2, MODE_STATS = 3 };
 
 struct TraceArgs {
     const float* rays;      // 7 floats per ray
+    const uint32_t* perm;   // packet slot -> ray index (coherence order), or null
     int n_rays;
     const float4* spheres;
+    const float4* A;        // pre-pass: {x, y, z, h*h}, padded by 4 entries
+    const float2* B;        // pre-pass: {1/h, (1/h)^2}, padded by 4 entries
     const float4* nodes;    // 4 x float4 per node
     int n_nodes;
     const int4* leaves;
@@ -113,22 +126,130 @@ __device__ __forceinline__ int aabbs_hit(const float ix, const float iy, const f
 }
 
 // OnHit_sphere_cumulate / _individual arithmetic (functors/trace.cuh:181-186) with lerp
-// (include/grace/generic/interpolate.h:11-39, device branch).  lut[i] = (y_i, y_{i+1} - y_i).
-__device__ __forceinline__ float hit_integral(const float b2, const float h, const double2* lut)
+// (include/grace/generic/interpolate.h:11-39, device branch).  lut[i] = (y_i, y_{i+1} - y_i);
+// ir = 1/h and ir2 = ir*ir come from the pre-pass (same fp32 operations).  The lerp weight
+// t = double(b) - int(b) is formed as float(b - float(int(b))), which is exact (b < 64,
+// Sterbenz), then widened: one fp64 conversion instead of two and an fp64 subtract.
+__device__ __forceinline__ float hit_integral(const float b2, const float ir, const float ir2,
+                                              const double2* lut)
 {
-    const float ir = 1.f / h;
-    float b = (N_TABLE - 1) * (__builtin_sqrtf(b2) * ir);
+    const float b = (N_TABLE - 1) * (__builtin_sqrtf(b2) * ir);
     int x_idx = static_cast<int>(b);
+    float t32 = b - static_cast<float>(x_idx);
     if (x_idx >= N_TABLE - 1) {
-        b = static_cast<float>(N_TABLE - 1);
+        t32 = 1.0f; // x = N_table - 1, x_idx = N_table - 2
         x_idx = N_TABLE - 2;
     }
     const double2 y = lut[x_idx];
-    const double t = static_cast<double>(b) - x_idx;
-    float integral = static_cast<float>(__builtin_fma(t, y.y, y.x));
-    integral *= (ir * ir);
+    float integral = static_cast<float>(__builtin_fma(static_cast<double>(t32), y.y, y.x));
+    integral *= ir2;
     return integral;
 }
+
+__global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __restrict__ spheres,
+                                                            size_t n, float4* __restrict__ A,
+                                                            float2* __restrict__ B)
+{
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n + 4;
+         i += size_t(gridDim.x) * blockDim.x) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 b = make_float2(0.f, 0.f);
+        if (i < n) {
+            const float4 s = spheres[i];
+            a = make_float4(s.x, s.y, s.z, s.w * s.w); // sphere.w * sphere.w, intersect.h:37
+            if (B) {
+                const float ir = 1.f / s.w;            // functors/trace.cuh:181
+                b = make_float2(ir, ir * ir);          // functors/trace.cuh:184
+            }
+        }
+        A[i] = a;
+        if (B) B[i] = b;
+    }
+}
+
+// ---- ray coherence order ---------------------------------------------------------------
+// Packets are 64 consecutive rays of an ORDER chosen here, not of the caller's array: the
+// per-ray results do not depend on which rays share a packet (each equals the brute-force
+// loop), but the number of boxes and spheres a packet touches does.  Rays are keyed by a
+// Morton code over those of their six coordinates (origin, direction) that actually vary,
+// quantised over their extents, and sorted (stable radix sort, sort.hip).  The reference
+// leaves this to the caller (its generators sort by direction or end point,
+// include/grace/cuda/kernels/gen_rays.cuh:483,520,577,615).
+__device__ __forceinline__ uint32_t f2ord_u(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float ord2f_u(uint32_t u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ __launch_bounds__(256) void ray_extents_kernel(const float* __restrict__ rays, int n,
+                                                          uint32_t* __restrict__ ext12)
+{
+    float lo[6], hi[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* r = rays + 7 * size_t(i);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float v = r[k];
+            lo[k] = fminf(lo[k], v);
+            hi[k] = fmaxf(hi[k], v);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            atomicMin(&ext12[k], f2ord_u(lo[k]));
+            atomicMax(&ext12[6 + k], f2ord_u(hi[k]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__ rays, int n,
+                                                       const uint32_t* __restrict__ ext12,
+                                                       uint32_t* __restrict__ keys)
+{
+    float lo[6], scale[6];
+    int nvar = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        lo[k] = ord2f_u(ext12[k]);
+        const float span = ord2f_u(ext12[6 + k]) - lo[k];
+        const bool varies = span > 0.f && span < INFINITY;
+        scale[k] = varies ? 1.0f / span : 0.f;
+        nvar += varies ? 1 : 0;
+    }
+    const int bits = nvar ? min(10, 30 / nvar) : 0;
+    const float qmax = float((1 << bits) - 1);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* r = rays + 7 * size_t(i);
+        uint32_t q[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q[k] = uint32_t(fminf(qmax, (r[k] - lo[k]) * scale[k] * qmax));
+        uint32_t key = 0;
+        for (int b = bits - 1; b >= 0; --b) {
+#pragma unroll
+            for (int k = 5; k >= 0; --k) // origin x is the least significant dimension
+                if (scale[k] > 0.f) key = (key << 1) | ((q[k] >> b) & 1u);
+        }
+        keys[i] = key;
+    }
+}
+
+bool g_ray_reorder = true;
 
 template <int MODE>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
@@ -144,14 +265,20 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     }
 
     const int lane = threadIdx.x & 63;
-    const int packet = __builtin_amdgcn_readfirstlane(blockIdx.x * (TRACE_BLOCK / 64)
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only, never
+    // correctness): give each XCD a contiguous run of packets.
+    const int nb = gridDim.x, q = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int vblock = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+    const int packet = __builtin_amdgcn_readfirstlane(vblock * (TRACE_BLOCK / 64)
                                                       + (threadIdx.x >> 6));
     const int first_ray = packet * 64;
     if (first_ray >= a.n_rays) return;
-    const int ray_index = first_ray + lane;
-    const bool valid = ray_index < a.n_rays;
+    const int slot_index = first_ray + lane;
+    const bool valid = slot_index < a.n_rays;
     // Tail lanes re-trace the last ray so that they do not widen the packet.
-    const float* rp = a.rays + 7 * size_t(valid ? ray_index : a.n_rays - 1);
+    const int slot_clamped = valid ? slot_index : a.n_rays - 1;
+    const int ray_index = a.perm ? int(a.perm[slot_clamped]) : slot_clamped;
+    const float* rp = a.rays + 7 * size_t(ray_index);
     const float dx = rp[0], dy = rp[1], dz = rp[2];
     const float ox = rp[3], oy = rp[4], oz = rp[5];
     const float len = rp[6];
@@ -160,7 +287,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     int count = 0;
     float sum = 0.f;
     int write_at = 0;
-    if (MODE == MODE_HITS) write_at = a.offsets[valid ? ray_index : a.n_rays - 1];
+    if (MODE == MODE_HITS) write_at = a.offsets[ray_index];
     uint32_t st_nodes = 0, st_leaves = 0, st_tested = 0;
 
     // Packet stack: entry e lives in lane (e & 63) of stk0 (e < 64) or stk1.
@@ -168,6 +295,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     // MODE_STATS: per entry, the lanes that reach it on their own.
     int ml0 = 0, mh0 = 0, ml1 = 0, mh1 = 0;
     int sp = -1;
+    int junk = 0;
     bool overflow = false;
 
     // v_writelane is not exposed as a builtin by this hipcc; a push is a lane-select
@@ -229,35 +357,77 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
         } else {
             const int4 leaf = a.leaves[idx - a.n_nodes];
             if (MODE == MODE_STATS && alive) { ++st_leaves; st_tested += uint32_t(leaf.y); }
-            const float4* sp4 = a.spheres + leaf.x;
-            for (int i = 0; i < leaf.y; ++i) {
-                const float4 s = sp4[i];
-                // sphere_hit, include/grace/generic/intersect.h:16-54
-                const float px = s.x - ox, py = s.y - oy, pz = s.z - oz;
-                const float dot_p = px * dx + py * dy + pz * dz;
-                const float bx = px - dot_p * dx;
-                const float by = py - dot_p * dy;
-                const float bz = pz - dot_p * dz;
-                const float b2 = bx * bx + by * by + bz * bz;
-                const bool hit = !(b2 >= s.w * s.w) && !(dot_p < 0.0f) && !(dot_p >= len);
-                if (MODE == MODE_COUNT || MODE == MODE_STATS) {
-                    count += hit ? 1 : 0;
-                } else if (hit) {
-                    const float w = hit_integral(b2, s.w, s_lut);
-                    if (MODE == MODE_CUMULATIVE) {
-                        sum += w;
-                    } else if (valid) {
-                        a.hit_idx[write_at] = leaf.x + i;
-                        a.hit_integral[write_at] = w;
-                        a.hit_dist[write_at] = dot_p;
-                        ++write_at;
+            // Touch the next stack entry's cache line now; its pop follows this leaf.
+            int warm = 0;
+            if (sp >= 0) {
+                const int nxt = sp < 64 ? __builtin_amdgcn_readlane(stk0, sp)
+                                        : __builtin_amdgcn_readlane(stk1, sp - 64);
+                warm = nxt < a.n_nodes
+                    ? reinterpret_cast<const int*>(a.nodes)[16 * size_t(nxt)]
+                    : reinterpret_cast<const int*>(a.leaves)[4 * size_t(nxt - a.n_nodes)];
+            }
+            const float4* pa = a.A + leaf.x;
+            const float2* pb = a.B + leaf.x;
+            constexpr bool NEED_B = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
+            float4 ca[4];
+            float2 cb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ca[k] = pa[k];
+                if (NEED_B) cb[k] = pb[k];
+            }
+            for (int i = 0; i < leaf.y; i += 4) {
+                float4 na[4];
+                float2 nb2[4];
+                const bool more = i + 4 < leaf.y;
+                if (more) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        na[k] = pa[i + 4 + k];
+                        if (NEED_B) nb2[k] = pb[i + 4 + k];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (i + k < leaf.y) {
+                        const float4 s = ca[k];
+                        // sphere_hit, include/grace/generic/intersect.h:16-54; s.w = h*h
+                        const float px = s.x - ox, py = s.y - oy, pz = s.z - oz;
+                        const float dot_p = px * dx + py * dy + pz * dz;
+                        const float bx = px - dot_p * dx;
+                        const float by = py - dot_p * dy;
+                        const float bz = pz - dot_p * dz;
+                        const float b2 = bx * bx + by * by + bz * bz;
+                        const bool hit = !(b2 >= s.w) && !(dot_p < 0.0f) && !(dot_p >= len);
+                        if (MODE == MODE_COUNT || MODE == MODE_STATS) {
+                            count += hit ? 1 : 0;
+                        } else if (hit) {
+                            const float w = hit_integral(b2, cb[k].x, cb[k].y, s_lut);
+                            if (MODE == MODE_CUMULATIVE) {
+                                sum += w;
+                            } else if (valid) {
+                                a.hit_idx[write_at] = leaf.x + i + k;
+                                a.hit_integral[write_at] = w;
+                                a.hit_dist[write_at] = dot_p;
+                                ++write_at;
+                            }
+                        }
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        ca[k] = na[k];
+                        if (NEED_B) cb[k] = nb2[k];
                     }
                 }
             }
+            // Keep the warming load alive (child / primitive indices are never negative).
+            junk |= warm;
         }
     }
 
-    if (overflow && lane == 0) *a.status = GRACE_STACK_OVERFLOW;
+    if ((overflow || junk < 0) && lane == 0) *a.status = GRACE_STACK_OVERFLOW;
     if (!valid) return;
     if (MODE == MODE_COUNT) a.out_counts[ray_index] = count;
     if (MODE == MODE_CUMULATIVE) a.out_sums[ray_index] = sum;
@@ -287,6 +457,36 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     GRACE_REQUIRE(n_nodes >= 1 && n_nodes < (size_t(1) << 30), "trace: bad node count");
     GRACE_REQUIRE(n_spheres > 0, "trace: no primitives");
     GRACE_TRY(ensure_status(stream));
+    {
+        constexpr bool need_b = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
+        const bool reorder = g_ray_reorder && n_rays > 64;
+        GRACE_TRY(Workspace::begin(Workspace::aligned((n_spheres + 4) * sizeof(float4))
+                                   + Workspace::aligned((n_spheres + 4) * sizeof(float2))
+                                   + (reorder ? 2 * Workspace::aligned(n_rays * 4)
+                                                + sort_ws_bytes(n_rays, 4, 0) : 0) + 1024));
+        float4* A = Workspace::take<float4>(n_spheres + 4);
+        float2* B = need_b ? Workspace::take<float2>(n_spheres + 4) : nullptr;
+        if (reorder) {
+            uint32_t* ext = Workspace::take<uint32_t>(12);
+            uint32_t* keys = Workspace::take<uint32_t>(n_rays);
+            uint32_t* perm = Workspace::take<uint32_t>(n_rays);
+            GRACE_TRY_HIP(hipMemsetAsync(ext, 0xFF, 24, stream));
+            GRACE_TRY_HIP(hipMemsetAsync(ext + 6, 0x00, 24, stream));
+            ray_extents_kernel<<<stream_grid(n_rays, 256, 4), 256, 0, stream>>>(a.rays, int(n_rays),
+                                                                              ext);
+            GRACE_CHECK_LAUNCH();
+            ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(a.rays, int(n_rays), ext,
+                                                                        keys);
+            GRACE_CHECK_LAUNCH();
+            GRACE_TRY(sort_pairs_u32_nested(keys, nullptr, n_rays, 0, 0, 30, perm, stream));
+            a.perm = perm;
+        }
+        trace_prepass_kernel<<<stream_grid(n_spheres + 4, 256), 256, 0, stream>>>(
+            a.spheres, n_spheres, A, B);
+        GRACE_CHECK_LAUNCH();
+        a.A = A;
+        a.B = B;
+    }
     a.n_rays = int(n_rays);
     a.n_nodes = int(n_nodes);
     a.status = g_status;
@@ -368,6 +568,12 @@ grace_status grace_trace_stats_f4(const void* d_rays, size_t n_rays, const float
     a.root = d_root;
     a.stats = d_stats4;
     return launch_trace<MODE_STATS>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_trace_set_ray_reorder(int enabled)
+{
+    g_ray_reorder = enabled != 0;
+    return GRACE_OK;
 }
 
 grace_status grace_trace_status(grace_stream stream)

@@ -243,6 +243,10 @@ def _trace_args(rays, spheres, tree):
             _ptr(tree.nodes), C.c_size_t(tree.n_nodes), _ptr(tree.leaves), _ptr(tree.root_index))
 
 
+def set_ray_reorder(enabled):
+    _check(_lib.grace_trace_set_ray_reorder(C.c_int(1 if enabled else 0)))
+
+
 def trace_status():
     _check(_lib.grace_trace_status(_stream()))
 

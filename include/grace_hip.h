@@ -148,6 +148,12 @@ grace_status grace_trace_stats_f4(const void* d_rays, size_t n_rays, const float
                                   const int* d_leaves, const int* d_root,
                                   uint32_t* d_stats4, grace_stream stream);
 
+/* Packets are formed from 64 consecutive rays of a coherence order computed inside every
+ * trace call (Morton code over the varying ray coordinates + stable sort); results per ray
+ * do not depend on it.  0 disables it: packets then follow the caller's ray order, as in
+ * the reference.  Default 1.  Not part of the reference API. */
+grace_status grace_trace_set_ray_reorder(int enabled);
+
 /* Reads (and clears) the traversal status word: GRACE_STACK_OVERFLOW if any packet ran out
  * of its 128-entry stack since the last check (the reference only asserts this in
  * GRACE_DEBUG builds, bintree_trace.cuh:164).  Synchronises. */

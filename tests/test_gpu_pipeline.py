@@ -150,8 +150,15 @@ def _rays_from(origin, dirs, length):
     return r
 
 
+@pytest.fixture(params=[True, False], ids=["reorder", "caller-order"])
+def ray_order(request, gh):
+    gh.set_ray_reorder(request.param)
+    yield request.param
+    gh.set_ray_reorder(True)
+
+
 @pytest.mark.parametrize("n,n_rays,mpl", [(20000, 1024, 32), (20000, 96, 1), (100000, 3200, 32)])
-def test_trace_hitcounts_equal_brute_force(gh, oracle, cuda, n, n_rays, mpl):
+def test_trace_hitcounts_equal_brute_force(gh, oracle, cuda, ray_order, n, n_rays, mpl):
     """The reference's own criterion (tests/tree_traversal/tree_traversal.cu:65-100) on
     the hitcounts workload (tests/hitcounts/hitcounts.cu:47-58)."""
     s = _spheres(oracle, n)
@@ -176,7 +183,7 @@ def test_trace_tree_traversal_config(gh, oracle, cuda):
     assert np.array_equal(hc.cpu().numpy(), oracle.brute_hitcounts(rays.cpu().numpy(), ss))
 
 
-def test_trace_cumulative_bitexact_and_tolerance(gh, oracle, cuda):
+def test_trace_cumulative_bitexact_and_tolerance(gh, oracle, cuda, ray_order):
     n, n_side = 60000, 32
     s = _spheres(oracle, n, (0, 0, 0, 0.01), (1, 1, 1, 0.05))
     d, tree, ss, *_ = _build_both(gh, oracle, cuda, s, 32)
