@@ -34,6 +34,13 @@
 //     s_load_dwordx8) with the next chunk's loads issued before the current chunk is
 //     processed; while a leaf is processed the next stack entry's cache line is touched
 //     so that the following pop finds it in the scalar cache;
+//   * beam culling: once per packet the bounding boxes of the 64 origins and 64 directions
+//     are reduced across the wave; at a leaf, lane j takes sphere j and bounds, by interval
+//     arithmetic over the whole beam, the smallest impact parameter any ray of the packet can
+//     have (minus a rounding margin far larger than the fp32 error of sphere_hit).  Spheres
+//     that no ray of the packet can hit are dropped with ONE vector test per leaf; only the
+//     survivors (ballot mask, s_ff1) get the 64-ray test.  Per-ray results are unchanged:
+//     a dropped sphere is one for which sphere_hit is false for every ray of the packet;
 //   * packets are dealt to workgroups so that the workgroups sharing an XCD (blockIdx % 8)
 //     walk a contiguous range of packets: neighbouring packets touch the same subtree and
 //     each XCD's 4 MiB L2 keeps it.
@@ -130,10 +137,30 @@ __device__ __forceinline__ int aabbs_hit(const float ix, const float iy, const f
 // ir = 1/h and ir2 = ir*ir come from the pre-pass (same fp32 operations).  The lerp weight
 // t = double(b) - int(b) is formed as float(b - float(int(b))), which is exact (b < 64,
 // Sterbenz), then widened: one fp64 conversion instead of two and an fp64 subtract.
+// Correctly rounded sqrt for x = 0 or x >= 2^-96 (finite): v_sqrt_f32 is within 1 ulp, the
+// two FMA residuals pick the neighbour if it is closer -- the core of hipcc's own expansion
+// without its input scaling and class test (seven instructions the hit path executes for
+// every candidate).  x = 0 falls through unchanged (the residuals are NaN / -0).
+__device__ __forceinline__ float sqrt_rn_normal(const float x)
+{
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __int_as_float(__float_as_int(y) - 1);
+    const float yp = __int_as_float(__float_as_int(y) + 1);
+    const float rm = __builtin_fmaf(-ym, y, x);
+    const float rp = __builtin_fmaf(-yp, y, x);
+    float r = (0.0f >= rm) ? ym : y;
+    r = (0.0f < rp) ? yp : r;
+    return r;
+}
+
 __device__ __forceinline__ float hit_integral(const float b2, const float ir, const float ir2,
                                               const double2* lut)
 {
-    const float b = (N_TABLE - 1) * (__builtin_sqrtf(b2) * ir);
+    // Tiny non-zero b2 (a ray within ~1e-15 of a centre) takes the general sqrtf; the branch
+    // is wave-uniform and practically never taken.
+    const bool tiny = b2 < 1.2621774e-29f && b2 > 0.0f; // 2^-96
+    const float root = __builtin_amdgcn_ballot_w64(tiny) ? __builtin_sqrtf(b2) : sqrt_rn_normal(b2);
+    const float b = (N_TABLE - 1) * (root * ir);
     int x_idx = static_cast<int>(b);
     float t32 = b - static_cast<float>(x_idx);
     if (x_idx >= N_TABLE - 1) {
@@ -209,12 +236,19 @@ __global__ __launch_bounds__(256) void ray_extents_kernel(const float* __restric
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
         }
     }
+    __shared__ float s_lo[4][6], s_hi[4][6];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            atomicMin(&ext12[k], f2ord_u(lo[k]));
-            atomicMax(&ext12[6 + k], f2ord_u(hi[k]));
-        }
+        for (int k = 0; k < 6; ++k) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float l = s_lo[0][k], h = s_hi[0][k];
+        for (int w = 1; w < 4; ++w) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
+        atomicMin(&ext12[k], f2ord_u(l));
+        atomicMax(&ext12[6 + k], f2ord_u(h));
     }
 }
 
@@ -249,7 +283,73 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
     }
 }
 
+// The per-hit arithmetic on plain arrays (tests pin it against the oracle on inputs no
+// traversal would produce: zeros, denormals, b2 -> h^2, huge/small h).
+__global__ __launch_bounds__(256) void hit_integrals_kernel(const float* __restrict__ b2,
+                                                            const float* __restrict__ h, size_t n,
+                                                            float* __restrict__ out)
+{
+    __shared__ double2 s_lut[N_TABLE];
+    if (threadIdx.x < N_TABLE) {
+        const double y0 = c_kernel_table[threadIdx.x];
+        const double y1 = threadIdx.x + 1 < N_TABLE ? c_kernel_table[threadIdx.x + 1] : y0;
+        s_lut[threadIdx.x] = make_double2(y0, y1 - y0);
+    }
+    __syncthreads();
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x) {
+        const float ir = 1.f / h[i];
+        out[i] = hit_integral(b2[i], ir, ir * ir, s_lut);
+    }
+}
+
 bool g_ray_reorder = true;
+
+// Bounding boxes of the packet's origins and directions (wave-uniform, SGPRs).
+struct Beam {
+    float olo[3], ohi[3], dlo[3], dhi[3];
+};
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// Conservative: returns false only if sphere_hit (generic/intersect.h:10-55) is false for
+// every ray with origin in [olo, ohi] and direction in [dlo, dhi].
+//   true b^2 = |p|^2 - (p.d)^2, p = c - o.  Lower bound over the beam:
+//   |p|^2_lo - max((p.d)_lo^2, (p.d)_hi^2), component-wise interval arithmetic.
+// sphere_hit's computed b2 differs from the true value by < ~16 u |p|^2 (u = 2^-24; |b| <= |p|)
+// and the interval end points carry similar rounding; the margin 2^-18 |p|^2_hi covers both
+// with a factor > 16 to spare.  Any NaN keeps the sphere.
+__device__ __forceinline__ bool beam_may_hit(const float4 s, const Beam& bm)
+{
+    float p2_lo = 0.f, p2_hi = 0.f, t_lo = 0.f, t_hi = 0.f;
+    const float c[3] = { s.x, s.y, s.z };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float plo = c[k] - bm.ohi[k], phi = c[k] - bm.olo[k];
+        const float a2 = plo * plo, b2 = phi * phi;
+        p2_hi += fmaxf(a2, b2);
+        p2_lo += (plo <= 0.f && phi >= 0.f) ? 0.f : fminf(a2, b2);
+        const float q0 = plo * bm.dlo[k], q1 = plo * bm.dhi[k];
+        const float q2 = phi * bm.dlo[k], q3 = phi * bm.dhi[k];
+        t_lo += fminf(fminf(q0, q1), fminf(q2, q3));
+        t_hi += fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
+    }
+    const float t2_hi = fmaxf(t_lo * t_lo, t_hi * t_hi);
+    const float b2_lo = p2_lo - t2_hi - 3.814697265625e-06f * p2_hi; // 2^-18
+    return !(b2_lo >= s.w);
+}
 
 template <int MODE>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
@@ -283,6 +383,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     const float ox = rp[3], oy = rp[4], oz = rp[5];
     const float len = rp[6];
     const float ix = 1.f / dx, iy = 1.f / dy, iz = 1.f / dz; // bintree_trace.cuh:111-114
+
+    Beam beam;
+    beam.olo[0] = wave_min(ox); beam.ohi[0] = wave_max(ox);
+    beam.olo[1] = wave_min(oy); beam.ohi[1] = wave_max(oy);
+    beam.olo[2] = wave_min(oz); beam.ohi[2] = wave_max(oz);
+    beam.dlo[0] = wave_min(dx); beam.dhi[0] = wave_max(dx);
+    beam.dlo[1] = wave_min(dy); beam.dhi[1] = wave_max(dy);
+    beam.dlo[2] = wave_min(dz); beam.dhi[2] = wave_max(dz);
 
     int count = 0;
     float sum = 0.f;
@@ -369,28 +477,31 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             const float4* pa = a.A + leaf.x;
             const float2* pb = a.B + leaf.x;
             constexpr bool NEED_B = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
-            float4 ca[4];
-            float2 cb[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                ca[k] = pa[k];
-                if (NEED_B) cb[k] = pb[k];
-            }
-            for (int i = 0; i < leaf.y; i += 4) {
-                float4 na[4];
-                float2 nb2[4];
-                const bool more = i + 4 < leaf.y;
-                if (more) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        na[k] = pa[i + 4 + k];
-                        if (NEED_B) nb2[k] = pb[i + 4 + k];
+            for (int base = 0; base < leaf.y; base += 64) {
+                const int m = min(64, leaf.y - base);
+                // Lane j: can ANY ray of the beam come within h of sphere j?
+                const float4 mine = pa[base + (lane < m ? lane : 0)];
+                const bool keep = lane < m && beam_may_hit(mine, beam);
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(keep);
+                if (todo == 0ull) continue;
+                int j = base + __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                float4 cur = pa[j];
+                float2 curb = make_float2(0.f, 0.f);
+                if (NEED_B) curb = pb[j];
+                for (;;) {
+                    const bool more = todo != 0ull;
+                    int jn = 0;
+                    float4 nxt4 = cur;
+                    float2 nxtb = curb;
+                    if (more) { // issue the next survivor's scalar loads before the math
+                        jn = base + __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        nxt4 = pa[jn];
+                        if (NEED_B) nxtb = pb[jn];
                     }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (i + k < leaf.y) {
-                        const float4 s = ca[k];
+                    {
+                        const float4 s = cur;
                         // sphere_hit, include/grace/generic/intersect.h:16-54; s.w = h*h
                         const float px = s.x - ox, py = s.y - oy, pz = s.z - oz;
                         const float dot_p = px * dx + py * dy + pz * dz;
@@ -402,24 +513,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         if (MODE == MODE_COUNT || MODE == MODE_STATS) {
                             count += hit ? 1 : 0;
                         } else if (hit) {
-                            const float w = hit_integral(b2, cb[k].x, cb[k].y, s_lut);
+                            const float w = hit_integral(b2, curb.x, curb.y, s_lut);
                             if (MODE == MODE_CUMULATIVE) {
                                 sum += w;
                             } else if (valid) {
-                                a.hit_idx[write_at] = leaf.x + i + k;
+                                a.hit_idx[write_at] = leaf.x + j;
                                 a.hit_integral[write_at] = w;
                                 a.hit_dist[write_at] = dot_p;
                                 ++write_at;
                             }
                         }
                     }
-                }
-                if (more) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        ca[k] = na[k];
-                        if (NEED_B) cb[k] = nb2[k];
-                    }
+                    if (!more) break;
+                    cur = nxt4;
+                    curb = nxtb;
+                    j = jn;
                 }
             }
             // Keep the warming load alive (child / primitive indices are never negative).
@@ -472,7 +580,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             uint32_t* perm = Workspace::take<uint32_t>(n_rays);
             GRACE_TRY_HIP(hipMemsetAsync(ext, 0xFF, 24, stream));
             GRACE_TRY_HIP(hipMemsetAsync(ext + 6, 0x00, 24, stream));
-            ray_extents_kernel<<<stream_grid(n_rays, 256, 4), 256, 0, stream>>>(a.rays, int(n_rays),
+            ray_extents_kernel<<<(stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256), 256, 0, stream>>>(a.rays, int(n_rays),
                                                                               ext);
             GRACE_CHECK_LAUNCH();
             ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(a.rays, int(n_rays), ext,
@@ -568,6 +676,16 @@ grace_status grace_trace_stats_f4(const void* d_rays, size_t n_rays, const float
     a.root = d_root;
     a.stats = d_stats4;
     return launch_trace<MODE_STATS>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_hit_integrals_f32(const float* d_b2, const float* d_h, size_t n, float* d_out,
+                                     grace_stream stream)
+{
+    GRACE_REQUIRE(n == 0 || (d_b2 && d_h && d_out), "hit_integrals: null pointer");
+    if (n == 0) return GRACE_OK;
+    hit_integrals_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(d_b2, d_h, n, d_out);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
 }
 
 grace_status grace_trace_set_ray_reorder(int enabled)

@@ -243,6 +243,13 @@ def _trace_args(rays, spheres, tree):
             _ptr(tree.nodes), C.c_size_t(tree.n_nodes), _ptr(tree.leaves), _ptr(tree.root_index))
 
 
+def hit_integrals(b2, h):
+    """functors/trace.cuh:181-186 on arrays (device tensors), the traversal's own arithmetic."""
+    out = torch.empty_like(b2)
+    _check(_lib.grace_hit_integrals_f32(_ptr(b2), _ptr(h), C.c_size_t(len(b2)), _ptr(out), _stream()))
+    return out
+
+
 def set_ray_reorder(enabled):
     _check(_lib.grace_trace_set_ray_reorder(C.c_int(1 if enabled else 0)))
 

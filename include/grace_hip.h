@@ -148,6 +148,12 @@ grace_status grace_trace_stats_f4(const void* d_rays, size_t n_rays, const float
                                   const int* d_leaves, const int* d_root,
                                   uint32_t* d_stats4, grace_stream stream);
 
+/* The per-hit kernel integral of OnHit_sphere_cumulate / OnHit_sphere_individual
+ * (include/grace/cuda/functors/trace.cuh:181-186, 221-224) evaluated on arrays:
+ * out[i] = lerp(50 * sqrt(b2[i]) / h[i], table) / h[i]^2, bit-for-bit the traversal's value. */
+grace_status grace_hit_integrals_f32(const float* d_b2, const float* d_h, size_t n, float* d_out,
+                                     grace_stream stream);
+
 /* Packets are formed from 64 consecutive rays of a coherence order computed inside every
  * trace call (Morton code over the varying ray coordinates + stable sort); results per ray
  * do not depend on it.  0 disables it: packets then follow the caller's ray order, as in

@@ -521,6 +521,12 @@ static inline float hit_integral(float b2, float h)
 
 float go_hit_integral(float b2, float h) { return hit_integral(b2, h); }
 
+void go_hit_integral_array(const float* b2, const float* h, size_t n, float* out)
+{
+    #pragma omp parallel for
+    for (size_t i = 0; i < n; ++i) out[i] = hit_integral(b2[i], h[i]);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Brute force (the reference's own correctness criterion)                    */
 /* ------------------------------------------------------------------------- */

@@ -211,3 +211,27 @@ def test_trace_rejects_bad_ray_count(gh, oracle, cuda):
     rays = gh.uniform_random_rays(33, (0.5, 0.5, 0.5), 2.0, device=cuda)
     with pytest.raises(ValueError):   # bintree_trace.cuh:231-238
         gh.trace_hitcounts_sph(rays, d, tree, torch.empty(33, dtype=torch.int32, device=cuda))
+
+
+def test_hit_integral_arithmetic_bitexact(gh, oracle, cuda):
+    """sqrt, 1/h, the fp64 lerp and the final products against the oracle on 4M inputs,
+    including the edges: b2 = 0, denormal and tiny b2, b2 just below h^2, table clamp."""
+    rng = np.random.default_rng(5)
+    n = 1 << 22
+    h = np.exp(rng.uniform(np.log(1e-6), np.log(1e6), n)).astype(np.float32)
+    frac = rng.uniform(0, 1, n).astype(np.float32)
+    b2 = (frac * h) ** 2
+    b2 = b2.astype(np.float32)
+    b2[:1000] = 0.0
+    b2[1000:2000] = np.float32(1e-40)            # denormal
+    b2[2000:3000] = rng.uniform(1e-38, 1e-28, 1000).astype(np.float32)
+    b2[3000:4000] = np.nextafter((h[3000:4000] * h[3000:4000]).astype(np.float32), np.float32(0))
+    b2[4000:5000] = (h[4000:5000] * h[4000:5000]).astype(np.float32)   # table clamp branch
+    got = gh.hit_integrals(_dev(b2, cuda), _dev(h, cuda)).cpu().numpy()
+    L = oracle.lib()
+    import ctypes as C
+    L.go_hit_integral_array.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    ref = np.empty(n, np.float32)
+    L.go_hit_integral_array(b2.ctypes.data, h.ctypes.data, n, ref.ctypes.data)
+    bad = np.nonzero(got.view(np.uint32) != ref.view(np.uint32))[0]
+    assert len(bad) == 0, (bad[:5], b2[bad[:5]], h[bad[:5]], got[bad[:5]], ref[bad[:5]])
