@@ -117,13 +117,14 @@ def main():
     del keys, deltas
 
     # ---- rays: the full grid, then this rank's contiguous shard (multiple of 64) --------
+    from grace_hip import sharding
     rays, area = gh.orthogonal_rays_z(args.side, lo, hi, device=device)
     n_rays = len(rays)
-    per = ((n_rays + world - 1) // world + 63) // 64 * 64
-    r0 = min(rank * per, n_rays); r1 = min(r0 + per, n_rays)
+    per = sharding.shard_size(n_rays, world)
+    r0, r1 = sharding.shard_bounds(n_rays, world, rank)
     my_rays = rays[r0:r1].contiguous()
     my_out = torch.zeros(per, dtype=torch.float32, device=device)
-    image = torch.empty(per * world, dtype=torch.float32, device=device) if world > 1 else my_out
+    image = my_out
 
     # ---- algorithmic bytes, counted per ray by the instrumented walk ------
     stats = gh.trace_stats(my_rays, spheres, tree).to(torch.int64).sum(dim=0)
@@ -135,11 +136,10 @@ def main():
 
     def step():
         gh.trace_cumulative_sph(my_rays, spheres, tree, my_out[: r1 - r0])
-        if world > 1:
-            dist.all_gather_into_tensor(image, my_out)
+        return sharding.gather_results(my_out, n_rays, world, dist)
 
     for _ in range(args.warmup):
-        step()
+        image = step()
     kern_ev = [(ev(), ev()) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
@@ -150,8 +150,7 @@ def main():
         kern_ev[k][0].record()
         gh.trace_cumulative_sph(my_rays, spheres, tree, my_out[: r1 - r0])
         kern_ev[k][1].record()
-        if world > 1:
-            dist.all_gather_into_tensor(image, my_out)
+        image = sharding.gather_results(my_out, n_rays, world, dist)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -178,7 +177,7 @@ def main():
                 traffic = json.load(open(tfile)).get("trace_cumulative_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        img = (image[:n_rays] if world > 1 else my_out[:n_rays])
+        img = image[:n_rays]
         out = {
             "metric": "Mrays/s SPH column-density trace, 10^7 particles",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
@@ -205,7 +204,6 @@ def main():
             "image": {"mean": float(img.mean()), "max": float(img.max())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            n_s = min(n, len(spheres))
             out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), rays.cpu().numpy())
         print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,407 @@
+// grace.h -- host-only C++ mirror of the grace:: header API for the BVH-build + SPH
+// ray-traversal hot path, forwarding to the C ABI of libgrace_hip.so (include/grace_hip.h).
+//
+// Same names, argument meaning and error behaviour as the reference headers it replaces
+// (paths relative to the reference root):
+//   include/grace/ray.h, types.h                     -> grace::Ray, uinteger32/64
+//   include/grace/cuda/nodes.h                       -> grace::Tree
+//   include/grace/cuda/build_sph.cuh                 -> morton_keys*_sph, *_deltas_sph, ALBVH_sph
+//   include/grace/cuda/trace_sph.cuh                 -> trace_hitcounts_sph, trace_cumulative_sph,
+//                                                       trace_sph
+//   include/grace/cuda/scan.cuh                      -> exclusive_segmented_scan
+//   tests/helper/tree.cuh, tests/helper/rays.cuh     -> build_tree, orthogonal_rays_z
+//   (no reference symbol; named by the task)         -> project_sph
+//
+// The reference's boundary type is thrust::device_vector; this mirror is HIP-free (plain
+// g++ compiles it), so it ships grace::device_vector<T>, a minimal owning device array with
+// the subset of the thrust interface the reference's call sites use (size, resize, data,
+// assignment from / copy to std::vector).  Errors: a bad argument throws
+// std::invalid_argument exactly where the reference does; a GPU API failure prints the
+// message and exit()s like GRACE_CUDA_CHECK (include/grace/error.h:40-56).
+#pragma once
+
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "grace_hip.h"
+
+namespace grace {
+
+typedef uint32_t uinteger32; // include/grace/types.h:29-32
+typedef uint64_t uinteger64;
+
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+struct int4 { int x, y, z, w; };
+
+inline float3 make_float3(float x, float y, float z) { float3 v = { x, y, z }; return v; }
+inline float4 make_float4(float x, float y, float z, float w) { float4 v = { x, y, z, w }; return v; }
+
+// include/grace/ray.h:5-10
+struct Ray {
+    float dx, dy, dz;
+    float ox, oy, oz;
+    float length;
+};
+
+namespace detail {
+
+inline void check(grace_status s)
+{
+    if (s == GRACE_OK) return;
+    if (s == GRACE_INVALID_ARGUMENT) throw std::invalid_argument(grace_last_error());
+    // include/grace/error.h:40-56: print and exit with the error code.
+    std::fprintf(stderr, "**** GRACE HIP Error ****\n%s\n", grace_last_error());
+    std::exit(int(s));
+}
+
+} // namespace detail
+
+// Minimal stand-in for thrust::device_vector<T> (device memory owned through the C ABI).
+template <typename T>
+class device_vector {
+public:
+    device_vector() : ptr_(nullptr), size_(0), capacity_(0) {}
+    explicit device_vector(size_t n) : ptr_(nullptr), size_(0), capacity_(0)
+    {
+        resize(n);
+        if (n) detail::check(grace_memset(ptr_, 0, n * sizeof(T), nullptr)); // value-init
+    }
+    device_vector(const std::vector<T>& h) : ptr_(nullptr), size_(0), capacity_(0) { *this = h; }
+    device_vector(const device_vector& o) : ptr_(nullptr), size_(0), capacity_(0)
+    {
+        resize(o.size_);
+        detail::check(grace_memcpy_dtod(ptr_, o.ptr_, size_ * sizeof(T), nullptr));
+    }
+    ~device_vector() { grace_device_free(ptr_); }
+
+    device_vector& operator=(const std::vector<T>& h)
+    {
+        resize(h.size());
+        detail::check(grace_memcpy_htod(ptr_, h.data(), h.size() * sizeof(T), nullptr));
+        return *this;
+    }
+    device_vector& operator=(const device_vector& o)
+    {
+        if (this != &o) {
+            resize(o.size_);
+            detail::check(grace_memcpy_dtod(ptr_, o.ptr_, size_ * sizeof(T), nullptr));
+        }
+        return *this;
+    }
+
+    // Keeps the old contents (thrust semantics); new elements are unspecified.
+    void resize(size_t n)
+    {
+        if (n > capacity_) {
+            void* p = nullptr;
+            detail::check(grace_device_malloc(&p, n * sizeof(T)));
+            if (size_) detail::check(grace_memcpy_dtod(p, ptr_, size_ * sizeof(T), nullptr));
+            detail::check(grace_stream_synchronize(nullptr));
+            grace_device_free(ptr_);
+            ptr_ = static_cast<T*>(p);
+            capacity_ = n;
+        }
+        size_ = n;
+    }
+    size_t size() const { return size_; }
+    T* data() { return ptr_; }
+    const T* data() const { return ptr_; }
+
+    std::vector<T> to_host() const
+    {
+        std::vector<T> h(size_);
+        detail::check(grace_memcpy_dtoh(h.data(), ptr_, size_ * sizeof(T), nullptr));
+        return h;
+    }
+    T at_host(size_t i) const
+    {
+        T v;
+        detail::check(grace_memcpy_dtoh(&v, ptr_ + i, sizeof(T), nullptr));
+        return v;
+    }
+
+private:
+    T* ptr_;
+    size_t size_, capacity_;
+};
+
+// include/grace/cuda/nodes.h:14-58.  nodes holds 4 int4 per node, leaves one int4 per leaf;
+// both are allocated for N leaves and shrunk by the build (albvh.cuh:842-845).
+class Tree {
+public:
+    device_vector<int4> nodes;
+    device_vector<int4> leaves;
+    int* root_index_ptr;
+    int max_per_leaf;
+
+    Tree(size_t N_leaves, int max_per_leaf_ = 1)
+        : nodes(4 * (N_leaves - 1)), leaves(N_leaves), root_index_ptr(nullptr),
+          max_per_leaf(max_per_leaf_)
+    {
+        void* p = nullptr;
+        detail::check(grace_device_malloc(&p, sizeof(int)));
+        root_index_ptr = static_cast<int*>(p);
+    }
+    ~Tree() { grace_device_free(root_index_ptr); }
+
+private:
+    Tree(const Tree&);
+    Tree& operator=(const Tree&);
+};
+
+// ---- build: include/grace/cuda/build_sph.cuh -------------------------------------------
+
+// build_sph.cuh:27-35 (30-bit keys)
+inline void morton_keys_sph(const device_vector<float4>& d_spheres, const float3 bot,
+                            const float3 top, device_vector<uinteger32>& d_keys)
+{
+    const float b[3] = { bot.x, bot.y, bot.z }, t[3] = { top.x, top.y, top.z };
+    detail::check(grace_morton_keys30_f4(&d_spheres.data()->x, d_spheres.size(), b, t,
+                                         d_keys.data(), nullptr));
+}
+
+// build_sph.cuh:27-35 (63-bit keys)
+inline void morton_keys_sph(const device_vector<float4>& d_spheres, const float3 bot,
+                            const float3 top, device_vector<uinteger64>& d_keys)
+{
+    const float b[3] = { bot.x, bot.y, bot.z }, t[3] = { top.x, top.y, top.z };
+    detail::check(grace_morton_keys63_f4(&d_spheres.data()->x, d_spheres.size(), b, t,
+                                         d_keys.data(), nullptr));
+}
+
+// build_sph.cuh:19-25: bounds from the centroids (kernels/morton.cuh:139-174)
+template <typename KeyType>
+inline void morton_keys_sph(const device_vector<float4>& d_spheres, device_vector<KeyType>& d_keys)
+{
+    float b[3], t[3];
+    detail::check(grace_centroid_bounds_f4(&d_spheres.data()->x, d_spheres.size(), b, t, nullptr));
+    morton_keys_sph(d_spheres, make_float3(b[0], b[1], b[2]), make_float3(t[0], t[1], t[2]),
+                    d_keys);
+}
+
+// build_sph.cuh:50-58
+inline void morton_keys30_sort_sph(device_vector<float4>& d_spheres, const float3 bot,
+                                   const float3 top)
+{
+    device_vector<uinteger32> d_keys;
+    d_keys.resize(d_spheres.size());
+    morton_keys_sph(d_spheres, bot, top, d_keys);
+    detail::check(grace_sort_pairs_u32(d_keys.data(), d_spheres.data(), d_spheres.size(),
+                                       sizeof(float4), 0, 30, nullptr, nullptr));
+}
+
+// build_sph.cuh:41-47
+inline void morton_keys30_sort_sph(device_vector<float4>& d_spheres)
+{
+    device_vector<uinteger32> d_keys;
+    d_keys.resize(d_spheres.size());
+    morton_keys_sph(d_spheres, d_keys);
+    detail::check(grace_sort_pairs_u32(d_keys.data(), d_spheres.data(), d_spheres.size(),
+                                       sizeof(float4), 0, 30, nullptr, nullptr));
+}
+
+// build_sph.cuh:74-82
+inline void morton_keys63_sort_sph(device_vector<float4>& d_spheres, const float3 bot,
+                                   const float3 top)
+{
+    device_vector<uinteger64> d_keys;
+    d_keys.resize(d_spheres.size());
+    morton_keys_sph(d_spheres, bot, top, d_keys);
+    detail::check(grace_sort_pairs_u64(d_keys.data(), d_spheres.data(), d_spheres.size(),
+                                       sizeof(float4), 0, 63, nullptr, nullptr));
+}
+
+// build_sph.cuh:87-94
+inline void euclidean_deltas_sph(const device_vector<float4>& d_spheres,
+                                 device_vector<float>& d_deltas)
+{
+    detail::check(grace_deltas_euclid_f4(&d_spheres.data()->x, d_spheres.size(), d_deltas.data(),
+                                         nullptr));
+}
+
+// build_sph.cuh:98-105
+inline void surface_area_deltas_sph(const device_vector<float4>& d_spheres,
+                                    device_vector<float>& d_deltas)
+{
+    detail::check(grace_deltas_area_f4(&d_spheres.data()->x, d_spheres.size(), d_deltas.data(),
+                                       nullptr));
+}
+
+// build_sph.cuh:109-114
+inline void XOR_deltas_sph(const device_vector<uinteger32>& d_keys,
+                           device_vector<uinteger32>& d_deltas)
+{
+    detail::check(grace_deltas_xor_u32(d_keys.data(), d_keys.size(), d_deltas.data(), nullptr));
+}
+
+inline void XOR_deltas_sph(const device_vector<uinteger64>& d_keys,
+                           device_vector<uinteger64>& d_deltas)
+{
+    detail::check(grace_deltas_xor_u64(d_keys.data(), d_keys.size(), d_deltas.data(), nullptr));
+}
+
+// build_sph.cuh:118-124 -> build_ALBVH (kernels/albvh.cuh:986-1021)
+inline void ALBVH_sph(const device_vector<float4>& d_spheres, const device_vector<float>& d_deltas,
+                      Tree& d_tree)
+{
+    size_t n_leaves = 0;
+    detail::check(grace_albvh_build_f4(&d_spheres.data()->x, d_spheres.size(), d_deltas.data(),
+                                       d_tree.max_per_leaf, &d_tree.nodes.data()->x,
+                                       &d_tree.leaves.data()->x, d_tree.root_index_ptr, &n_leaves,
+                                       nullptr));
+    d_tree.nodes.resize(4 * (n_leaves - 1));
+    d_tree.leaves.resize(n_leaves);
+}
+
+inline void ALBVH_sph(const device_vector<float4>& d_spheres,
+                      const device_vector<uinteger32>& d_deltas, Tree& d_tree)
+{
+    size_t n_leaves = 0;
+    detail::check(grace_albvh_build_f4_u32(&d_spheres.data()->x, d_spheres.size(), d_deltas.data(),
+                                           d_tree.max_per_leaf, &d_tree.nodes.data()->x,
+                                           &d_tree.leaves.data()->x, d_tree.root_index_ptr,
+                                           &n_leaves, nullptr));
+    d_tree.nodes.resize(4 * (n_leaves - 1));
+    d_tree.leaves.resize(n_leaves);
+}
+
+// ---- trace: include/grace/cuda/trace_sph.cuh --------------------------------------------
+
+namespace detail {
+
+inline void check_ray_count(size_t n_rays)
+{
+    // include/grace/cuda/kernels/bintree_trace.cuh:231-238
+    if (n_rays % 32 != 0)
+        throw std::invalid_argument("Number of rays must be a multiple of the warp size (32).");
+}
+
+} // namespace detail
+
+// trace_sph.cuh:58-80
+inline void trace_hitcounts_sph(const device_vector<Ray>& d_rays,
+                                const device_vector<float4>& d_spheres, const Tree& d_tree,
+                                device_vector<int>& d_hit_counts)
+{
+    detail::check_ray_count(d_rays.size());
+    detail::check(grace_trace_hitcounts_f4(d_rays.data(), d_rays.size(), &d_spheres.data()->x,
+                                           d_spheres.size(), &d_tree.nodes.data()->x,
+                                           d_tree.leaves.size() - 1, &d_tree.leaves.data()->x,
+                                           d_tree.root_index_ptr, d_hit_counts.data(), nullptr));
+    detail::check(grace_trace_status(nullptr));
+}
+
+// trace_sph.cuh:82-110
+inline void trace_cumulative_sph(const device_vector<Ray>& d_rays,
+                                 const device_vector<float4>& d_spheres, const Tree& d_tree,
+                                 device_vector<float>& d_cumulated)
+{
+    detail::check_ray_count(d_rays.size());
+    detail::check(grace_trace_cumulative_f4(d_rays.data(), d_rays.size(), &d_spheres.data()->x,
+                                            d_spheres.size(), &d_tree.nodes.data()->x,
+                                            d_tree.leaves.size() - 1, &d_tree.leaves.data()->x,
+                                            d_tree.root_index_ptr, d_cumulated.data(), nullptr));
+    detail::check(grace_trace_status(nullptr));
+}
+
+// trace_sph.cuh:112-168
+inline void trace_sph(const device_vector<Ray>& d_rays, const device_vector<float4>& d_spheres,
+                      const Tree& d_tree, device_vector<int>& d_ray_offsets,
+                      device_vector<int>& d_hit_indices, device_vector<float>& d_hit_integrals,
+                      device_vector<float>& d_hit_distances)
+{
+    trace_hitcounts_sph(d_rays, d_spheres, d_tree, d_ray_offsets);
+    long long total = 0;
+    detail::check(grace_scan_exclusive_i32(d_ray_offsets.data(), d_ray_offsets.size(),
+                                           d_ray_offsets.data(), &total, nullptr));
+    d_hit_integrals.resize(size_t(total));
+    d_hit_indices.resize(size_t(total));
+    d_hit_distances.resize(size_t(total));
+    detail::check(grace_trace_hits_f4(d_rays.data(), d_rays.size(), &d_spheres.data()->x,
+                                      d_spheres.size(), &d_tree.nodes.data()->x,
+                                      d_tree.leaves.size() - 1, &d_tree.leaves.data()->x,
+                                      d_tree.root_index_ptr, d_ray_offsets.data(),
+                                      d_hit_indices.data(), d_hit_integrals.data(),
+                                      d_hit_distances.data(), nullptr));
+    detail::check(grace_trace_status(nullptr));
+}
+
+// ---- scan: include/grace/cuda/scan.cuh:15-37 --------------------------------------------
+inline void exclusive_segmented_scan(const device_vector<int>& d_segment_offsets,
+                                     device_vector<float>& d_data, device_vector<float>& d_results)
+{
+    detail::check(grace_segscan_exclusive_f32(d_segment_offsets.data(), d_segment_offsets.size(),
+                                              d_data.data(), d_data.size(), d_results.data(),
+                                              nullptr));
+}
+
+inline void exclusive_segmented_scan(const device_vector<int>& d_segment_offsets,
+                                     device_vector<double>& d_data,
+                                     device_vector<double>& d_results)
+{
+    detail::check(grace_segscan_exclusive_f64(d_segment_offsets.data(), d_segment_offsets.size(),
+                                              d_data.data(), d_data.size(), d_results.data(),
+                                              nullptr));
+}
+
+// util/extrema.cuh min_vec4 / max_vec4 as used by tests/project_gadget/project_gadget.cu:66-68
+inline void min_max_vec4(const device_vector<float4>& d_v, float4* mins, float4* maxs)
+{
+    detail::check(grace_minmax_f4(&d_v.data()->x, d_v.size(), &mins->x, &maxs->x, nullptr));
+}
+
+} // namespace grace
+
+// ---- test helpers the task names as API (global namespace in the reference) -------------
+
+// tests/helper/tree.cuh:30-43
+inline void build_tree(grace::device_vector<grace::float4>& spheres, const grace::float4 low,
+                       const grace::float4 high, grace::Tree& tree)
+{
+    grace::device_vector<float> deltas;
+    deltas.resize(spheres.size() + 1);
+    grace::morton_keys30_sort_sph(spheres, grace::make_float3(low.x, low.y, low.z),
+                                  grace::make_float3(high.x, high.y, high.z));
+    grace::euclidean_deltas_sph(spheres, deltas);
+    grace::ALBVH_sph(spheres, deltas, tree);
+}
+
+// tests/helper/tree.cuh:15-25
+inline void build_tree(grace::device_vector<grace::float4>& spheres, grace::Tree& tree)
+{
+    grace::device_vector<float> deltas;
+    deltas.resize(spheres.size() + 1);
+    grace::morton_keys30_sort_sph(spheres);
+    grace::euclidean_deltas_sph(spheres, deltas);
+    grace::ALBVH_sph(spheres, deltas, tree);
+}
+
+// tests/helper/rays.cuh:55-79
+inline void orthogonal_rays_z(const size_t N_side, const grace::float4 mins,
+                              const grace::float4 maxs, grace::device_vector<grace::Ray>& d_rays,
+                              float* area = NULL)
+{
+    d_rays.resize(N_side * N_side);
+    grace::detail::check(grace_rays_orthogonal_z(int(N_side), &mins.x, &maxs.x, d_rays.data(), area,
+                                                 nullptr));
+}
+
+// The projection of tests/project_gadget/project_gadget.cu:58-81 as one call: bounds with
+// w = 0, build_tree (sorts d_spheres), orthogonal_rays_z, trace_cumulative_sph.
+inline void project_sph(grace::device_vector<grace::float4>& d_spheres, const size_t N_side,
+                        const int max_per_leaf, grace::device_vector<float>& d_image)
+{
+    grace::float4 mins, maxs;
+    grace::min_max_vec4(d_spheres, &mins, &maxs);
+    mins.w = maxs.w = 0;
+    grace::Tree tree(d_spheres.size(), max_per_leaf);
+    build_tree(d_spheres, mins, maxs, tree);
+    grace::device_vector<grace::Ray> rays;
+    orthogonal_rays_z(N_side, mins, maxs, rays);
+    d_image.resize(rays.size());
+    grace::trace_cumulative_sph(rays, d_spheres, tree, d_image);
+}

@@ -1,0 +1,274 @@
+"""GPU parity, part 2: per-hit trace, scans, ray generators, the committed fixtures, the C++
+header mirror, and size-independent properties at BASELINE.json's full sizes."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def _build(gh, cuda, s, mpl, low=(0, 0, 0), high=(1, 1, 1)):
+    d = _dev(s, cuda)
+    tree = gh.Tree(len(s), mpl, device=cuda)
+    gh.build_tree(d, tree, low, high)
+    return d, tree
+
+
+# ---- committed fixtures -------------------------------------------------------------------
+def test_golden_pipeline_on_gpu(gh, cuda):
+    g = np.load(os.path.join(GOLD, "pipeline_n4096.npz"))
+    s = g["spheres"]
+    d = _dev(s, cuda)
+    k30 = torch.empty(len(s), dtype=torch.int32, device=cuda)
+    k63 = torch.empty(len(s), dtype=torch.int64, device=cuda)
+    gh.morton_keys_sph(d, k30, (0, 0, 0), (1, 1, 1))
+    gh.morton_keys_sph(d, k63, (0, 0, 0), (1, 1, 1))
+    assert np.array_equal(k30.cpu().numpy().view(np.uint32), g["keys30"])
+    assert np.array_equal(k63.cpu().numpy().view(np.uint64), g["keys63"])
+    perm = gh.sort_by_key(k30, d, 0, 30, want_perm=True)
+    assert np.array_equal(perm.cpu().numpy().view(np.uint32), g["order"])
+    dl = torch.empty(len(s) + 1, dtype=torch.float32, device=cuda)
+    gh.euclidean_deltas_sph(d, dl)
+    assert np.array_equal(dl.cpu().numpy().view(np.uint32), g["deltas"].view(np.uint32))
+    for mpl in (1, 8, 32):
+        tree = gh.Tree(len(s), mpl, device=cuda)
+        gh.ALBVH_sph(d, dl, tree)
+        assert np.array_equal(tree.nodes.cpu().numpy(), g["nodes_%d" % mpl])
+        assert np.array_equal(tree.leaves.cpu().numpy(), g["leaves_%d" % mpl])
+        assert int(tree.root_index.item()) == int(g["root_%d" % mpl])
+        rays = _dev(g["rays"], cuda)
+        hc = torch.empty(len(rays), dtype=torch.int32, device=cuda)
+        gh.trace_hitcounts_sph(rays, d, tree, hc)
+        assert np.array_equal(hc.cpu().numpy(), g["hit_counts"])
+        cu = torch.empty(len(rays), dtype=torch.float32, device=cuda)
+        gh.trace_cumulative_sph(rays, d, tree, cu)
+        assert np.array_equal(cu.cpu().numpy().view(np.uint32), g["cumulative32"].view(np.uint32))
+        assert np.allclose(cu.cpu().numpy(), g["cumulative64"], rtol=1e-5, atol=0)
+    so = _dev(g["seg_offsets"], cuda); sd = _dev(g["seg_data"], cuda)
+    out = torch.empty_like(sd)
+    gh.exclusive_segmented_scan(so, sd, out)
+    assert np.array_equal(out.cpu().numpy(), g["seg_result"])
+
+
+def test_healpix_rays_against_reference_run(gh, cuda):
+    ref = np.load(os.path.join(GOLD, "healpix_nside4_ref.npy"))     # reference chealpix output
+    rays = gh.healpix_rays(4, (0.5, 0.25, 0.125), 3.0, device=cuda).cpu().numpy()
+    assert rays.shape == (192, 7)
+    # device cos/sin/sqrt in fp64, then rounded to fp32: at most 1 ulp from the reference
+    assert np.allclose(rays[:, :3], ref.astype(np.float32), rtol=0, atol=1.2e-7)
+    assert np.all(rays[:, 3:6] == np.array([0.5, 0.25, 0.125], np.float32)) and np.all(rays[:, 6] == 3.0)
+
+
+def test_isotropic_rays_are_unit_sorted_and_reproducible(gh, oracle, cuda):
+    a = gh.uniform_random_rays(4096, (0, 0, 0), 1.0, seed=11, device=cuda).cpu().numpy()
+    b = gh.uniform_random_rays(4096, (0, 0, 0), 1.0, seed=11, device=cuda).cpu().numpy()
+    c = gh.uniform_random_rays(4096, (0, 0, 0), 1.0, seed=12, device=cuda).cpu().numpy()
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.allclose(np.linalg.norm(a[:, :3], axis=1), 1.0, atol=3e-7)
+    keys = oracle.ray_dir_keys(a)                     # gen_rays.cuh:38-43
+    assert np.all(np.diff(keys.astype(np.int64)) >= 0)
+    assert np.abs(a[:, :3].mean(axis=0)).max() < 0.05   # isotropy, first moment
+
+
+# ---- trace_sph (two-pass per-hit output) ------------------------------------------------------
+@pytest.mark.parametrize("n,n_rays,mpl", [(30000, 512, 32), (5000, 64, 1)])
+def test_trace_sph_hits(gh, oracle, cuda, n, n_rays, mpl):
+    s = oracle.random_real4(n, (0, 0, 0, 0), (1, 1, 1, 0.08))
+    d, tree = _build(gh, cuda, s, mpl)
+    rays = gh.uniform_random_rays(n_rays, (0.5, 0.5, 0.5), 2.0, seed=3, device=cuda)
+    offs, idx, integ, dist = gh.trace_sph(rays, d, tree)
+    gh.trace_status()
+    ro, ri, rw, rd = oracle.brute_hits(rays.cpu().numpy(), d.cpu().numpy())
+    assert np.array_equal(offs.cpu().numpy(), ro)
+    assert np.array_equal(idx.cpu().numpy(), ri)           # ascending primitive index per ray
+    assert np.array_equal(integ.cpu().numpy().view(np.uint32), rw.view(np.uint32))
+    assert np.array_equal(dist.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+    assert np.all(dist.cpu().numpy() >= 0)                  # tests/distance_sort: none < 0
+    # per-ray exclusive scan of the integrals == optical depth in front of each hit
+    out = torch.empty_like(integ)
+    gh.exclusive_segmented_scan(offs, integ, out)
+    assert np.allclose(out.cpu().numpy(), oracle.segscan(ro, rw), rtol=2e-6, atol=1e-30)
+
+
+# ---- scans ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("count,max_seg", [(1, 1), (1000, 5), (10000, 3), (100000, 64),
+                                           (1 << 20, 2000), (3000000, 100000)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_segmented_scan_matches_host(gh, oracle, cuda, count, max_seg, dtype):
+    """tests/segmented_scan/segmented_scan.cu:65-162: random segment sizes incl. empties,
+    integer-valued data 1..9 (exact in fp), GPU == sequential host scan."""
+    rng = np.random.default_rng(count + max_seg)
+    sizes = []
+    total = 0
+    while total < count:
+        sz = int(rng.integers(0, min(max_seg, count - total) + 1))
+        sizes.append(sz); total += sz
+    sizes = np.array(sizes, np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
+    data = rng.integers(1, 10, count).astype(dtype)
+    so = _dev(offs, cuda); sd = _dev(data, cuda)
+    out = torch.empty_like(sd)
+    gh.exclusive_segmented_scan(so, sd, out)
+    assert np.array_equal(out.cpu().numpy(), oracle.segscan(offs, data))
+    gh.exclusive_segmented_scan(so, sd, sd)          # in place, as scan.cuh:13 allows
+    assert np.array_equal(sd.cpu().numpy(), oracle.segscan(offs, data))
+
+
+@pytest.mark.parametrize("n", [1, 63, 8192, 8193, 1 << 20, 5000001])
+def test_exclusive_scan(gh, oracle, cuda, n):
+    a = np.random.default_rng(n).integers(0, 400, n).astype(np.int32)   # total < 2^31
+    d = _dev(a, cuda)
+    total = gh.exclusive_scan(d, d)
+    ref, rt = oracle.exclusive_scan_i32(a)
+    assert total == rt and np.array_equal(d.cpu().numpy(), ref)
+
+
+def test_weighted_segmented_scan(gh, oracle, cuda):
+    rng = np.random.default_rng(9)
+    n = 50000
+    x = rng.integers(1, 5, n).astype(np.float32); w = rng.integers(1, 4, 100).astype(np.float32)
+    m = rng.integers(0, 100, n).astype(np.int32)
+    offs = np.arange(0, n, 500, dtype=np.int32)
+    out = torch.empty(n, dtype=torch.float32, device=cuda)
+    gh.weighted_exclusive_segmented_scan(_dev(x, cuda), _dev(w, cuda), _dev(m, cuda), _dev(offs, cuda), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.segscan(offs, w[m] * x))
+
+
+# ---- KATs on the GPU -------------------------------------------------------------------------
+def test_volume_integral_kat_on_gpu(gh, cuda):
+    """tests/integrate/integrate.cu: two spheres (max_per_leaf 1), normalised volume
+    integral == 1 +- 5e-4."""
+    tol = json.load(open(os.path.join(GOLD, "kat.json")))["integrate_tolerance"]
+    s = torch.tensor([[-0.5, -0.5, -0.5, 0.2], [0.5, 0.5, 0.5, 0.2]], dtype=torch.float32, device=cuda)
+    tree = gh.Tree(2, 1, device=cuda)
+    gh.build_tree(s, tree, (-1, -1, -1), (1, 1, 1))
+    rays, area = gh.orthogonal_rays_z(512, (-1, -1, -1, 0.2), (1, 1, 1, 0.2), device=cuda)
+    out = torch.empty(len(rays), dtype=torch.float32, device=cuda)
+    gh.trace_cumulative_sph(rays, s, tree, out)
+    integral = float(out.sum()) * area / 2
+    assert abs(1.0 - integral) < tol
+
+
+def test_integrate_gadget_like_kat(gh, cuda):
+    """tests/integrate_gadget: every particle's kernel integrates to one, so the normalised
+    volume integral over a snapshot is 1 (synthetic 32^3 jittered lattice)."""
+    g = torch.Generator(device=cuda); g.manual_seed(42)
+    n_side = 32
+    n = n_side ** 3
+    grid = torch.stack(torch.meshgrid(*[torch.arange(n_side, device=cuda)] * 3, indexing="ij"), -1)
+    pos = (grid.reshape(-1, 3).float() + torch.rand((n, 3), generator=g, device=cuda)) / n_side
+    h = (3 * 48 / (4 * np.pi * n)) ** (1 / 3)
+    s = torch.cat([pos, torch.full((n, 1), h, device=cuda)], 1).contiguous()
+    lo, hi = gh.min_max_vec4(s)
+    tree = gh.Tree(n, 32, device=cuda)
+    gh.build_tree(s, tree, lo[:3], hi[:3])
+    rays, area = gh.orthogonal_rays_z(512, lo, hi, device=cuda)   # w = max h pads the grid
+    out = torch.empty(len(rays), dtype=torch.float32, device=cuda)
+    gh.trace_cumulative_sph(rays, s, tree, out)
+    assert abs(1.0 - float(out.double().sum()) * area / n) < 5e-4
+
+
+# ---- the C++ header mirror, run on the GPU -------------------------------------------------------
+def test_cpp_tree_traversal_program(tmp_path):
+    lib = os.path.join(ROOT, "grace-devel_amd", "lib")
+    exe = tmp_path / "tree_traversal"
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "tree_traversal.cpp"), "-o", str(exe),
+                           "-L" + lib, "-lgrace_hip", "-L" + os.path.join(ROOT, "oracle"),
+                           "-lgrace_oracle", "-Wl,-rpath," + lib,
+                           "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    r = subprocess.run([str(exe), "100000", "50", "32"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+
+
+# ---- full BASELINE sizes: properties that need no brute force ------------------------------------
+def test_config2_full_size_properties(gh, oracle, cuda):
+    """LBVH build + hitcounts at 10^6 spheres / 10^5 rays (tests/hitcounts/hitcounts.cu):
+    sortedness and stability of the build sort, leaf partition, packet-order independence
+    (bitwise), per-hit sums vs cumulative, and exactness against the brute-force oracle on
+    an evenly spaced 512-ray subset."""
+    n, n_rays = 1000000, 100000 // 64 * 64 + 32     # = 100000 = 3125 * 32, not a multiple of 64
+    assert n_rays == 100000
+    s = oracle.random_real4(n, (0, 0, 0, 0), (1, 1, 1, 0.1))
+    d = _dev(s, cuda)
+    keys = torch.empty(n, dtype=torch.int32, device=cuda)
+    gh.morton_keys_sph(d, keys, (0, 0, 0), (1, 1, 1))
+    k0 = keys.clone()
+    perm = gh.sort_by_key(keys, d, 0, 30, want_perm=True)
+    kk = keys.cpu().numpy().astype(np.int64); pp = perm.cpu().numpy().astype(np.int64)
+    assert np.all(np.diff(kk) >= 0)                                   # sorted
+    assert np.all((np.diff(kk) > 0) | (np.diff(pp) > 0))              # stable
+    assert np.array_equal(np.sort(pp), np.arange(n))                  # a permutation
+    assert np.array_equal(k0.cpu().numpy()[pp], keys.cpu().numpy())
+    keys2 = keys.clone(); gh.sort_by_key(keys2, None, 0, 30)          # idempotent
+    assert torch.equal(keys2, keys)
+    dl = torch.empty(n + 1, dtype=torch.float32, device=cuda)
+    gh.euclidean_deltas_sph(d, dl)
+    tree = gh.Tree(n, 32, device=cuda)
+    gh.ALBVH_sph(d, dl, tree)
+    lv = tree.leaves.cpu().numpy()
+    assert lv[0, 0] == 0 and lv[:, 1].sum() == n and lv[:, 1].max() <= 32
+    assert np.all(lv[1:, 0] == lv[:-1, 0] + lv[:-1, 1])
+    nd = tree.nodes.cpu().numpy(); root = int(tree.root_index.item())
+    assert nd[root, 2] == 0 and nd[root, 3] == len(lv) - 1
+
+    rays = gh.uniform_random_rays(n_rays, (0.5, 0.5, 0.5), 2.0, seed=1234, device=cuda)
+    hc = torch.empty(n_rays, dtype=torch.int32, device=cuda)
+    cu = torch.empty(n_rays, dtype=torch.float32, device=cuda)
+    gh.trace_hitcounts_sph(rays, d, tree, hc); gh.trace_cumulative_sph(rays, d, tree, cu)
+    gh.set_ray_reorder(False)
+    hc2 = torch.empty_like(hc); cu2 = torch.empty_like(cu)
+    gh.trace_hitcounts_sph(rays, d, tree, hc2); gh.trace_cumulative_sph(rays, d, tree, cu2)
+    gh.set_ray_reorder(True)
+    gh.trace_status()
+    assert torch.equal(hc, hc2) and torch.equal(cu.view(torch.int32), cu2.view(torch.int32))
+    st = gh.trace_stats(rays, d, tree).cpu().numpy()
+    assert np.array_equal(st[:, 3], hc.cpu().numpy())
+    assert 5000 < hc.float().mean().item() < 8000                     # ~6.4e3 hits/ray
+    sub = np.linspace(0, n_rays - 1, 512).astype(np.int64)
+    rh = rays.cpu().numpy()[sub]; sh = d.cpu().numpy()
+    assert np.array_equal(hc.cpu().numpy()[sub], oracle.brute_hitcounts(rh, sh))
+    c32, c64 = oracle.brute_cumulative(rh, sh)
+    assert np.array_equal(cu.cpu().numpy()[sub].view(np.uint32), c32.view(np.uint32))
+
+
+def test_config4_full_size_properties(gh, oracle, cuda):
+    """project_gadget at 10^7 particles / 1024^2 rays through project_sph: image identical
+    for the two packet orders, linear under ray subsetting (a shard traced alone gives the
+    same pixels: the multi-GPU path), and exact against brute force on 48 pixels."""
+    n, side = 10_000_000, 1024
+    g = torch.Generator(device=cuda); g.manual_seed(42)
+    s = torch.empty((n, 4), dtype=torch.float32, device=cuda)
+    s[:, :3] = torch.rand((n, 3), generator=g, device=cuda)
+    s[:, 3] = float((3.0 * 48.0 / (4.0 * np.pi * n)) ** (1.0 / 3.0))
+    image, tree, rays = gh.project_sph(s, side, 32)
+    gh.trace_status()
+    img = image.reshape(-1)
+    from grace_hip import sharding
+    lo, hi = sharding.shard_bounds(len(rays), 8, 5)                 # what rank 5 of 8 would trace
+    part = torch.empty(hi - lo, dtype=torch.float32, device=cuda)
+    gh.trace_cumulative_sph(rays[lo:hi].contiguous(), s, tree, part)
+    assert torch.equal(part.view(torch.int32), img[lo:hi].view(torch.int32))
+    gh.set_ray_reorder(False)
+    part2 = torch.empty_like(part)
+    gh.trace_cumulative_sph(rays[lo:hi].contiguous(), s, tree, part2)
+    gh.set_ray_reorder(True)
+    assert torch.equal(part.view(torch.int32), part2.view(torch.int32))
+    sub = np.linspace(0, len(rays) - 1, 48).astype(np.int64)
+    c32, c64 = oracle.brute_cumulative(rays.cpu().numpy()[sub], s.cpu().numpy())
+    got = img.cpu().numpy()[sub]
+    assert np.allclose(got, c64, rtol=1e-5, atol=0)
+    assert np.array_equal(got.view(np.uint32), c32.view(np.uint32))
+    # mean column density of a unit box of n unit-mass particles viewed along z is n
+    assert abs(float(img.double().mean()) / n - 1.0) < 0.01
