@@ -41,6 +41,18 @@
 //     that no ray of the packet can hit are dropped with ONE vector test per leaf; only the
 //     survivors (ballot mask, s_ff1) get the 64-ray test.  Per-ray results are unchanged:
 //     a dropped sphere is one for which sphere_hit is false for every ray of the packet;
+//   * treelet sweep: a node whose subtree holds <= 64 primitives (their indices are
+//     contiguous) is not descended: its primitives go through one beam-culling pass as if
+//     they were a single leaf -- two to three levels of per-ray box tests and leaf records
+//     are replaced by one vector test.  Visiting order (ascending primitive index) and
+//     per-ray results are unchanged; the instrumented `stats` walk never uses it;
+//   * axis-aligned packets (every ray of the packet has the same direction +-e_k: the
+//     orthographic projections of tests/project_gadget, tests/integrate*): sphere_hit's
+//     arithmetic collapses exactly under IEEE rules (x*0 = +-0, y + +-0 = y, p - p = 0):
+//     dot_p = p_k d_k and b2 = q1^2 + q2^2 over the two other components, bit-for-bit the
+//     values of the general expression (a zero dot_p may differ in sign, which no comparison
+//     sees; the per-hit `distances` output keeps the general form).  10 instead of 22 vector
+//     instructions per candidate sphere;
 //   * packets are dealt to workgroups so that the workgroups sharing an XCD (blockIdx % 8)
 //     walk a contiguous range of packets: neighbouring packets touch the same subtree and
 //     each XCD's 4 MiB L2 keeps it.
@@ -49,6 +61,8 @@
 // bytes per ray: 28 + 64 * nodes + 16 * leaves + 16 * spheres tested + 4,
 // counted per ray by the `stats` instantiation below.
 #include "common.hpp"
+
+#include <type_traits>
 
 using namespace grace_hip;
 
@@ -83,6 +97,8 @@ struct TraceArgs {
     const uint32_t* perm;   // packet slot -> ray index (coherence order), or null
     int n_rays;
     const float4* spheres;
+    const int2* node_prims; // pre-pass: per node {first primitive, primitive count}
+    int treelet;            // nodes with <= treelet primitives are swept as one leaf (0: off)
     const float4* A;        // pre-pass: {x, y, z, h*h}, padded by 4 entries
     const float2* B;        // pre-pass: {1/h, (1/h)^2}, padded by 4 entries
     const float4* nodes;    // 4 x float4 per node
@@ -162,10 +178,13 @@ __device__ __forceinline__ float hit_integral(const float b2, const float ir, co
     const float root = __builtin_amdgcn_ballot_w64(tiny) ? __builtin_sqrtf(b2) : sqrt_rn_normal(b2);
     const float b = (N_TABLE - 1) * (root * ir);
     int x_idx = static_cast<int>(b);
+    // t = double(b) - x_idx is exact in fp32 (b < 64, Sterbenz) -> one widening conversion.
     float t32 = b - static_cast<float>(x_idx);
-    if (x_idx >= N_TABLE - 1) {
-        t32 = 1.0f; // x = N_table - 1, x_idx = N_table - 2
-        x_idx = N_TABLE - 2;
+    // Table end (b == N_table - 1 exactly, i.e. sqrt(b2)/h rounded to 1): x = 50, x_idx = 49,
+    // t = 1.  Practically never taken; the vote keeps it off the common path.
+    if (__builtin_amdgcn_ballot_w64(x_idx >= N_TABLE - 1)) {
+        t32 = x_idx >= N_TABLE - 1 ? 1.0f : t32;
+        x_idx = x_idx >= N_TABLE - 1 ? N_TABLE - 2 : x_idx;
     }
     const double2 y = lut[x_idx];
     float integral = static_cast<float>(__builtin_fma(static_cast<double>(t32), y.y, y.x));
@@ -192,6 +211,19 @@ __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __rest
         A[i] = a;
         if (B) B[i] = b;
     }
+}
+
+// Primitive range of every node: a node's leaves are consecutive (nodes.h:27-28) and so are
+// their primitives, [leaves[first].x, leaves[last].x + leaves[last].y).
+__global__ __launch_bounds__(256) void node_prims_kernel(const int4* __restrict__ nodes4,
+                                                         const int4* __restrict__ leaves, int n_nodes,
+                                                         int2* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int4 n0 = nodes4[4 * size_t(i)];
+    const int4 lf = leaves[n0.z], ll = leaves[n0.w];
+    out[i] = make_int2(lf.x, ll.x + ll.y - lf.x);
 }
 
 // ---- ray coherence order ---------------------------------------------------------------
@@ -304,6 +336,7 @@ __global__ __launch_bounds__(256) void hit_integrals_kernel(const float* __restr
 }
 
 bool g_ray_reorder = true;
+int g_treelet = 256;
 
 // Bounding boxes of the packet's origins and directions (wave-uniform, SGPRs).
 struct Beam {
@@ -392,6 +425,22 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     beam.dlo[1] = wave_min(dy); beam.dhi[1] = wave_max(dy);
     beam.dlo[2] = wave_min(dz); beam.dhi[2] = wave_max(dz);
 
+    // Axis-aligned packet?  (wave-uniform; tail lanes replicate a valid ray)
+    int axis = -1;
+    if (MODE != MODE_HITS) {
+        const unsigned long long all = ~0ull;
+        const bool zx = dx == 0.f, zy = dy == 0.f, zz = dz == 0.f;
+        if (__builtin_amdgcn_ballot_w64(zy && zz && fabsf(dx) == 1.f) == all) axis = 0;
+        else if (__builtin_amdgcn_ballot_w64(zx && zz && fabsf(dy) == 1.f) == all) axis = 1;
+        else if (__builtin_amdgcn_ballot_w64(zx && zy && fabsf(dz) == 1.f) == all) axis = 2;
+    }
+    // Permuted per-lane constants for the axis path: along-axis origin/direction, then the
+    // two perpendicular origins in component order.
+    const float oa = axis == 0 ? ox : axis == 1 ? oy : oz;
+    const float da = axis == 0 ? dx : axis == 1 ? dy : dz;
+    const float o1 = axis == 0 ? oy : ox;
+    const float o2 = axis == 2 ? oy : oz;
+
     int count = 0;
     float sum = 0.f;
     int write_at = 0;
@@ -447,24 +496,43 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
         --sp;
         const bool alive = (alive_mask >> lane) & 1ull;
 
+        int sweep_first = 0, sweep_count = 0;
+        bool sweep = false;
         if (idx < a.n_nodes) {
             const float4* np = a.nodes + 4 * size_t(idx);
+            // Node and span are fetched together (one scalar-load round trip).
             const float4 n0 = np[0];
             const float4 L = np[1];
             const float4 R = np[2];
             const float4 Z = np[3];
+            int2 span = make_int2(0, 0x7fffffff);
+            if (MODE != MODE_STATS && a.treelet > 0) span = a.node_prims[idx];
+            if (span.y <= a.treelet) {
+                sweep = true; sweep_first = span.x; sweep_count = span.y;
+            } else {
             const int lr = aabbs_hit(ix, iy, iz, ox, oy, oz, len, L, R, Z);
             const bool hit_r = lr & 1, hit_l = lr >= 2;
+#ifdef GRACE_PACKET_STATS
+            if (MODE == MODE_STATS) ++st_nodes;
+#else
             if (MODE == MODE_STATS && alive) ++st_nodes;
+#endif
             const unsigned long long vote_r = __builtin_amdgcn_ballot_w64(hit_r);
             const unsigned long long vote_l = __builtin_amdgcn_ballot_w64(hit_l);
             if (vote_r) push(__float_as_int(n0.y),
                              MODE == MODE_STATS ? __builtin_amdgcn_ballot_w64(hit_r && alive) : 0ull);
             if (vote_l) push(__float_as_int(n0.x),
                              MODE == MODE_STATS ? __builtin_amdgcn_ballot_w64(hit_l && alive) : 0ull);
+            }
         } else {
-            const int4 leaf = a.leaves[idx - a.n_nodes];
-            if (MODE == MODE_STATS && alive) { ++st_leaves; st_tested += uint32_t(leaf.y); }
+            const int4 lf = a.leaves[idx - a.n_nodes];
+            sweep = true; sweep_first = lf.x; sweep_count = lf.y;
+#ifndef GRACE_PACKET_STATS
+            if (MODE == MODE_STATS && alive) { ++st_leaves; st_tested += uint32_t(lf.y); }
+#endif
+        }
+        if (sweep) {
+            const int2 leaf = make_int2(sweep_first, sweep_count);
             // Touch the next stack entry's cache line now; its pop follows this leaf.
             int warm = 0;
             if (sp >= 0) {
@@ -474,6 +542,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     ? reinterpret_cast<const int*>(a.nodes)[16 * size_t(nxt)]
                     : reinterpret_cast<const int*>(a.leaves)[4 * size_t(nxt - a.n_nodes)];
             }
+            // The sweep is instantiated per packet kind (general / axis x, y, z) so that the
+            // component selection of the axis path is resolved at compile time.
+            auto sweep_range = [&](auto ax_tag) {
+                constexpr int AX = decltype(ax_tag)::value;
             const float4* pa = a.A + leaf.x;
             const float2* pb = a.B + leaf.x;
             constexpr bool NEED_B = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
@@ -483,6 +555,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                 const float4 mine = pa[base + (lane < m ? lane : 0)];
                 const bool keep = lane < m && beam_may_hit(mine, beam);
                 unsigned long long todo = __builtin_amdgcn_ballot_w64(keep);
+#ifdef GRACE_PACKET_STATS
+                if (MODE == MODE_STATS) { st_leaves += 1; st_tested += __builtin_popcountll(todo); }
+#endif
                 if (todo == 0ull) continue;
                 int j = base + __builtin_ctzll(todo);
                 todo &= todo - 1ull;
@@ -502,13 +577,24 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     }
                     {
                         const float4 s = cur;
-                        // sphere_hit, include/grace/generic/intersect.h:16-54; s.w = h*h
-                        const float px = s.x - ox, py = s.y - oy, pz = s.z - oz;
-                        const float dot_p = px * dx + py * dy + pz * dz;
-                        const float bx = px - dot_p * dx;
-                        const float by = py - dot_p * dy;
-                        const float bz = pz - dot_p * dz;
-                        const float b2 = bx * bx + by * by + bz * bz;
+                        float b2, dot_p;
+                        if (AX >= 0) {
+                            // sphere_hit collapsed for d = +-e_AX (see the file header)
+                            const float sa = AX == 0 ? s.x : AX == 1 ? s.y : s.z;
+                            const float s1 = AX == 0 ? s.y : s.x;
+                            const float s2 = AX == 2 ? s.y : s.z;
+                            const float q1 = s1 - o1, q2 = s2 - o2;
+                            dot_p = (sa - oa) * da;
+                            b2 = q1 * q1 + q2 * q2;
+                        } else {
+                            // sphere_hit, include/grace/generic/intersect.h:16-54; s.w = h*h
+                            const float px = s.x - ox, py = s.y - oy, pz = s.z - oz;
+                            dot_p = px * dx + py * dy + pz * dz;
+                            const float bx = px - dot_p * dx;
+                            const float by = py - dot_p * dy;
+                            const float bz = pz - dot_p * dz;
+                            b2 = bx * bx + by * by + bz * bz;
+                        }
                         const bool hit = !(b2 >= s.w) && !(dot_p < 0.0f) && !(dot_p >= len);
                         if (MODE == MODE_COUNT || MODE == MODE_STATS) {
                             count += hit ? 1 : 0;
@@ -529,6 +615,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     curb = nxtb;
                     j = jn;
                 }
+            }
+            };
+            switch (axis) {
+            case 0: sweep_range(std::integral_constant<int, 0>()); break;
+            case 1: sweep_range(std::integral_constant<int, 1>()); break;
+            case 2: sweep_range(std::integral_constant<int, 2>()); break;
+            default: sweep_range(std::integral_constant<int, -1>()); break;
             }
             // Keep the warming load alive (child / primitive indices are never negative).
             junk |= warm;
@@ -570,10 +663,17 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         const bool reorder = g_ray_reorder && n_rays > 64;
         GRACE_TRY(Workspace::begin(Workspace::aligned((n_spheres + 4) * sizeof(float4))
                                    + Workspace::aligned((n_spheres + 4) * sizeof(float2))
+                                   + Workspace::aligned(n_nodes * sizeof(int2))
                                    + (reorder ? 2 * Workspace::aligned(n_rays * 4)
                                                 + sort_ws_bytes(n_rays, 4, 0) : 0) + 1024));
         float4* A = Workspace::take<float4>(n_spheres + 4);
         float2* B = need_b ? Workspace::take<float2>(n_spheres + 4) : nullptr;
+        int2* node_prims = Workspace::take<int2>(n_nodes);
+        node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
+            reinterpret_cast<const int4*>(a.nodes), a.leaves, int(n_nodes), node_prims);
+        GRACE_CHECK_LAUNCH();
+        a.node_prims = node_prims;
+        a.treelet = (MODE == MODE_STATS) ? 0 : g_treelet;
         if (reorder) {
             uint32_t* ext = Workspace::take<uint32_t>(12);
             uint32_t* keys = Workspace::take<uint32_t>(n_rays);
@@ -685,6 +785,13 @@ grace_status grace_hit_integrals_f32(const float* d_b2, const float* d_h, size_t
     if (n == 0) return GRACE_OK;
     hit_integrals_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(d_b2, d_h, n, d_out);
     GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+grace_status grace_trace_set_treelet_size(int max_primitives)
+{
+    GRACE_REQUIRE(max_primitives >= 0, "treelet size must be >= 0");
+    g_treelet = max_primitives;
     return GRACE_OK;
 }
 

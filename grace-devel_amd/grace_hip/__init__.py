@@ -250,6 +250,10 @@ def hit_integrals(b2, h):
     return out
 
 
+def set_treelet_size(n):
+    _check(_lib.grace_trace_set_treelet_size(C.c_int(int(n))))
+
+
 def set_ray_reorder(enabled):
     _check(_lib.grace_trace_set_ray_reorder(C.c_int(1 if enabled else 0)))
 

@@ -160,6 +160,10 @@ grace_status grace_hit_integrals_f32(const float* d_b2, const float* d_h, size_t
  * the reference.  Default 1.  Not part of the reference API. */
 grace_status grace_trace_set_ray_reorder(int enabled);
 
+/* Subtrees with at most this many primitives are swept in one culling pass instead of being
+ * descended (results per ray unchanged).  0 disables; default 256. */
+grace_status grace_trace_set_treelet_size(int max_primitives);
+
 /* Reads (and clears) the traversal status word: GRACE_STACK_OVERFLOW if any packet ran out
  * of its 128-entry stack since the last check (the reference only asserts this in
  * GRACE_DEBUG builds, bintree_trace.cuh:164).  Synchronises. */
