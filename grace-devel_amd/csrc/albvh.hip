@@ -102,7 +102,26 @@ __device__ __forceinline__ void sphere_box(const float4 s, float* bot, float* to
     bot[2] = s.z - s.w; top[2] = s.z + s.w;
 }
 
-template <typename D>
+// TriangleAABB (tests/profile_trace_triangle/triangle.cu:3-35): min/max over v, v+e1, v+e2,
+// zero-extent axes inflated by AABB_EPSILON * |coordinate|.
+__device__ __forceinline__ void triangle_box(const float* __restrict__ t, float* bot, float* top)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v0 = t[k], v1 = t[k] + t[3 + k], v2 = t[k] + t[6 + k];
+        bot[k] = fminf(v0, fminf(v1, v2));
+        top[k] = fmaxf(v0, fmaxf(v1, v2));
+        if (bot[k] == top[k]) {
+            const float scale = fabsf(bot[k]);
+            bot[k] -= 0.000001f * scale;
+            top[k] += 0.000001f * scale;
+        }
+    }
+}
+
+enum { PRIM_SPHERE = 0, PRIM_TRIANGLE = 1 };
+
+template <typename D, int PRIM>
 __global__ __launch_bounds__(256) void nodes_climb_kernel(const float4* __restrict__ spheres,
                                                           const int4* __restrict__ leaves,
                                                           int n_leaves,
@@ -118,7 +137,8 @@ __global__ __launch_bounds__(256) void nodes_climb_kernel(const float4* __restri
     float top[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (int i = 0; i < leaf.y; ++i) {
         float b[3], t[3];
-        sphere_box(spheres[leaf.x + i], b, t);
+        if (PRIM == PRIM_SPHERE) sphere_box(spheres[leaf.x + i], b, t);
+        else triangle_box(reinterpret_cast<const float*>(spheres) + 9 * size_t(leaf.x + i), b, t);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             bot[c] = fminf(bot[c], b[c]);
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(256) void nodes_climb_kernel(const float4* __restri
     }
 }
 
-template <typename D>
+template <typename D, int PRIM = PRIM_SPHERE>
 grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, int mpl,
                          int* d_nodes, int* d_leaves, int* d_root, size_t* h_n_leaves,
                          hipStream_t stream)
@@ -213,7 +233,7 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
                          "build_ALBVH: fewer than two leaves (NaN deltas?)");
 
     GRACE_TRY_HIP(hipMemsetAsync(arrivals, 0, size_t(n_leaves) * 4, stream));
-    nodes_climb_kernel<D><<<ceil_div(n_leaves, 256), 256, 0, stream>>>(
+    nodes_climb_kernel<D, PRIM><<<ceil_div(n_leaves, 256), 256, 0, stream>>>(
         reinterpret_cast<const float4*>(d_spheres), reinterpret_cast<const int4*>(d_leaves),
         int(n_leaves), leaf_ds, d_nodes, arrivals, d_root);
     GRACE_CHECK_LAUNCH();
@@ -238,6 +258,14 @@ grace_status grace_albvh_build_f4_u32(const float* d_spheres, size_t n, const ui
 {
     return albvh_build<uint32_t>(d_spheres, n, d_deltas, max_per_leaf, d_nodes, d_leaves,
                                  d_root, h_n_leaves, as_stream(stream));
+}
+
+grace_status grace_albvh_build_tri_u32(const float* d_tris, size_t n, const uint32_t* d_deltas,
+                                       int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                       size_t* h_n_leaves, grace_stream stream)
+{
+    return albvh_build<uint32_t, PRIM_TRIANGLE>(d_tris, n, d_deltas, max_per_leaf, d_nodes,
+                                                d_leaves, d_root, h_n_leaves, as_stream(stream));
 }
 
 } // extern "C"

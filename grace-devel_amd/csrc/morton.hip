@@ -172,9 +172,103 @@ grace_status morton_keys(const float* d_spheres, size_t n, const Real* bot, cons
     return GRACE_OK;
 }
 
+// ---- triangle primitives: {v, e1, e2}, 9 floats (tests/profile_trace_triangle/triangle.cuh:11-25)
+// TriangleCentroid (triangle.cuh:92-102): v + (1./3.) * (e1 + e2), all fp32 (the scalar binds
+// to operator*(float, float3), tests/helper/vector_math.cuh:34-37).
+__device__ __forceinline__ void tri_centroid(const float* __restrict__ t, float* c)
+{
+    const float third = float(1. / 3.);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = t[k] + third * (t[3 + k] + t[6 + k]);
+}
+
+__global__ __launch_bounds__(256) void tri_minmax_kernel(const float* __restrict__ tris, size_t n,
+                                                         uint32_t* __restrict__ out8)
+{
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x) {
+        float c[3];
+        tri_centroid(tris + 9 * i, c);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], c[k]); hi[k] = fmaxf(hi[k], c[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+    __shared__ float s_lo[4][3], s_hi[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float l = s_lo[0][k], h = s_hi[0][k];
+        for (int w = 1; w < 4; ++w) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
+        atomicMin(&out8[k], f2ord(l));
+        atomicMax(&out8[4 + k], f2ord(h));
+    }
+}
+
+__global__ __launch_bounds__(256) void morton_keys_tri_kernel(const float* __restrict__ tris, size_t n,
+                                                              float minx, float miny, float minz,
+                                                              float sx, float sy, float sz,
+                                                              uint32_t* __restrict__ keys)
+{
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x) {
+        float c[3];
+        tri_centroid(tris + 9 * i, c);
+        const uint32_t x = static_cast<uint32_t>(sx * (c[0] - minx));
+        const uint32_t y = static_cast<uint32_t>(sy * (c[1] - miny));
+        const uint32_t z = static_cast<uint32_t>(sz * (c[2] - minz));
+        keys[i] = Interleave<uint32_t>::key(x, y, z);
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+grace_status grace_centroid_bounds_tri(const float* d_tris, size_t n, float* h_bot, float* h_top,
+                                       grace_stream stream)
+{
+    GRACE_REQUIRE(d_tris && n > 0 && h_bot && h_top, "centroid_bounds_tri: bad argument");
+    hipStream_t st = as_stream(stream);
+    GRACE_TRY(Workspace::begin(256));
+    uint32_t* d_out = Workspace::take<uint32_t>(8);
+    GRACE_TRY_HIP(hipMemsetAsync(d_out, 0xFF, 16, st));
+    GRACE_TRY_HIP(hipMemsetAsync(d_out + 4, 0x00, 16, st));
+    tri_minmax_kernel<<<stream_grid(n, 256, 4), 256, 0, st>>>(d_tris, n, d_out);
+    GRACE_CHECK_LAUNCH();
+    uint32_t h[8];
+    GRACE_TRY_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));
+    GRACE_TRY_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 3; ++k) { h_bot[k] = ord2f(h[k]); h_top[k] = ord2f(h[4 + k]); }
+    return GRACE_OK;
+}
+
+grace_status grace_morton_keys30_tri(const float* d_tris, size_t n, const float* h_bot,
+                                     const float* h_top, uint32_t* d_keys, grace_stream stream)
+{
+    GRACE_REQUIRE(d_tris && d_keys && h_bot && h_top, "morton_keys_tri: null pointer");
+    if (n == 0) return GRACE_OK;
+    const int span = (1u << 10) - 1;
+    const float sx = span / (h_top[0] - h_bot[0]);
+    const float sy = span / (h_top[1] - h_bot[1]);
+    const float sz = span / (h_top[2] - h_bot[2]);
+    morton_keys_tri_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
+        d_tris, n, h_bot[0], h_bot[1], h_bot[2], sx, sy, sz, d_keys);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
 
 grace_status grace_minmax_f4(const float* d_v4, size_t n, float* h_mins4, float* h_maxs4,
                              grace_stream stream)

@@ -14,6 +14,8 @@
 // Streaming kernels: 28 B written per ray.
 #include "common.hpp"
 
+#include <cmath>
+
 using namespace grace_hip;
 
 namespace {
@@ -80,6 +82,28 @@ __global__ __launch_bounds__(256) void healpix_kernel(int nside, float ox, float
         float* r = rays + 7 * size_t(t);
         r[0] = float(v[0]); r[1] = float(v[1]); r[2] = float(v[2]);
         r[3] = ox; r[4] = oy; r[5] = oz; r[6] = length;
+    }
+}
+
+// perspective_projection_rays_kernel (include/grace/cuda/kernels/gen_rays.cuh:362-395)
+__global__ __launch_bounds__(256) void pinhole_kernel(int res_x, int res_y, float aspect,
+                                                      float cx, float cy, float cz, float vx,
+                                                      float vy, float vz, float ux, float uy,
+                                                      float uz, float nx, float ny, float nz,
+                                                      float length, float* __restrict__ rays)
+{
+    const int n = res_x * res_y;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int i = t % res_x, j = t / res_x;
+        const float x = (2 * ((i + 0.5f) / res_x) - 1) * aspect;
+        const float y = 1 - 2 * ((j + 0.5f) / res_y);
+        const float dx = x * vx + y * ux + 1.f * nx;
+        const float dy = x * vy + y * uy + 1.f * ny;
+        const float dz = x * vz + y * uz + 1.f * nz;
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        float* r = rays + 7 * size_t(t);
+        r[0] = dx * inv; r[1] = dy * inv; r[2] = dz * inv;
+        r[3] = cx; r[4] = cy; r[5] = cz; r[6] = length;
     }
 }
 
@@ -171,6 +195,37 @@ grace_status grace_rays_healpix(int nside, float ox, float oy, float oz, float l
     const size_t n = 12 * size_t(nside) * nside;
     healpix_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
         nside, ox, oy, oz, length, static_cast<float*>(d_rays));
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+grace_status grace_rays_pinhole(int res_x, int res_y, const float* h_camera, const float* h_look_at,
+                                const float* h_view_up, float fovy, float length, void* d_rays,
+                                grace_stream stream)
+{
+    GRACE_REQUIRE(res_x > 0 && res_y > 0 && h_camera && h_look_at && h_view_up && d_rays,
+                  "pinhole rays: bad argument");
+    // pinhole_camera_rays, gen_rays.cuh:727-789 (Real = float; normalize3 in fp64 on the host)
+    const float* c = h_camera;
+    float vd[3] = { h_look_at[0] - c[0], h_look_at[1] - c[1], h_look_at[2] - c[2] };
+    const float* up = h_view_up;
+    float c1[3] = { vd[1] * up[2] - vd[2] * up[1], vd[2] * up[0] - vd[0] * up[2],
+                    vd[0] * up[1] - vd[1] * up[0] };
+    double N = 1. / std::sqrt(double(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]));
+    float v[3] = { float(c1[0] * N), float(c1[1] * N), float(c1[2] * N) };
+    float c2[3] = { v[1] * vd[2] - v[2] * vd[1], v[2] * vd[0] - v[0] * vd[2],
+                    v[0] * vd[1] - v[1] * vd[0] };
+    N = 1. / std::sqrt(double(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]));
+    float u[3] = { float(c2[0] * N), float(c2[1] * N), float(c2[2] * N) };
+    N = 1. / std::sqrt(double(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]));
+    float nn[3] = { float(vd[0] * N), float(vd[1] * N), float(vd[2] * N) };
+    const float pre = float(1. / std::tan(fovy / 2.));
+    for (int k = 0; k < 3; ++k) nn[k] *= pre;
+    const float aspect = float(res_x) / res_y;
+    const size_t n = size_t(res_x) * res_y;
+    pinhole_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
+        res_x, res_y, aspect, c[0], c[1], c[2], v[0], v[1], v[2], u[0], u[1], u[2], nn[0], nn[1],
+        nn[2], length, static_cast<float*>(d_rays));
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
 }

@@ -391,6 +391,24 @@ grace_status segscan(const int* d_offsets, size_t n_seg, const T* d_data, size_t
     return GRACE_OK;
 }
 
+// thrust::transform(offsets, counting_iterator(0), plus) of trace_with_sentinels_sph
+// (include/grace/cuda/trace_sph.cuh:205-208) and the sentinel fill of its resize calls
+// (trace_sph.cuh:212-214).
+__global__ __launch_bounds__(256) void add_iota_kernel(int* __restrict__ v, size_t n)
+{
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x)
+        v[i] += int(i);
+}
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ v, size_t n,
+                                                       uint32_t value)
+{
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x)
+        v[i] = value;
+}
+
 __global__ __launch_bounds__(256) void multiply_by_weights_kernel(
     const float* __restrict__ x, size_t n, const float* __restrict__ w,
     const uint32_t* __restrict__ map, float* __restrict__ out)
@@ -437,6 +455,25 @@ grace_status grace_segscan_exclusive_f64(const int* d_segment_offsets, size_t n_
 {
     return segscan<double>(d_segment_offsets, n_segments, d_data, n, d_results,
                            as_stream(stream));
+}
+
+grace_status grace_add_iota_i32(int* d_values, size_t n, grace_stream stream)
+{
+    GRACE_REQUIRE(n == 0 || d_values, "add_iota: null pointer");
+    if (n == 0) return GRACE_OK;
+    add_iota_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(d_values, n);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+grace_status grace_fill_u32(void* d_values, size_t n, uint32_t bits, grace_stream stream)
+{
+    GRACE_REQUIRE(n == 0 || d_values, "fill: null pointer");
+    if (n == 0) return GRACE_OK;
+    fill_u32_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
+        static_cast<uint32_t*>(d_values), n, bits);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
 }
 
 grace_status grace_multiply_by_weights_f32(const float* d_unweighted, size_t n,

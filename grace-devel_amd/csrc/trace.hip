@@ -90,7 +90,7 @@ __constant__ double c_kernel_table[N_TABLE] = {
     0.000000000000000E+000
 };
 
-enum { MODE_COUNT = 0, MODE_CUMULATIVE = 1, MODE_HITS = 2, MODE_STATS = 3 };
+enum { MODE_COUNT = 0, MODE_CUMULATIVE = 1, MODE_HITS = 2, MODE_STATS = 3, MODE_TRI = 4 };
 
 struct TraceArgs {
     const float* rays;      // 7 floats per ray
@@ -101,6 +101,7 @@ struct TraceArgs {
     int treelet;            // nodes with <= treelet primitives are swept as one leaf (0: off)
     const float4* A;        // pre-pass: {x, y, z, h*h}, padded by 4 entries
     const float2* B;        // pre-pass: {1/h, (1/h)^2}, padded by 4 entries
+    const double* T64;      // MODE_TRI pre-pass: {v, e1, e2} widened to fp64, 9 per triangle
     const float4* nodes;    // 4 x float4 per node
     int n_nodes;
     const int4* leaves;
@@ -211,6 +212,76 @@ __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __rest
         A[i] = a;
         if (B) B[i] = b;
     }
+}
+
+// ---- triangle primitives (tests/profile_trace_triangle) -----------------------------------
+// Pre-pass: a bounding sphere per triangle (for the beam culling: a ray that meets the
+// triangle passes within r of the centre; r^2 is inflated by 2^-10 against fp32 rounding) and
+// the triangle widened to fp64 (the reference's dot/cross products are fp64 products of
+// float operands, tests/helper/vector_math.cu:27-52; widening once is exact).
+__global__ __launch_bounds__(256) void tri_prepass_kernel(const float* __restrict__ tris, size_t n,
+                                                          float4* __restrict__ A,
+                                                          double* __restrict__ T64)
+{
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n + 4;
+         i += size_t(gridDim.x) * blockDim.x) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+            const float* t = tris + 9 * i;
+            float c[3], r2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c[k] = t[k] + (t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
+#pragma unroll
+            for (int vtx = 0; vtx < 3; ++vtx) {
+                float d2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float p = (vtx == 0 ? t[k] : vtx == 1 ? t[k] + t[3 + k] : t[k] + t[6 + k]) - c[k];
+                    d2 += p * p;
+                }
+                r2 = fmaxf(r2, d2);
+            }
+            a = make_float4(c[0], c[1], c[2], r2 * 1.0009765625f + 1e-37f);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) T64[9 * i + k] = double(t[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) T64[9 * i + k] = 0.0;
+        }
+        A[i] = a;
+    }
+}
+
+// Moeller-Trumbore with back-face culling, tests/profile_trace_triangle/triangle.cuh:54-88,
+// with the fp64 dot/cross of tests/helper/vector_math.cu narrowed to float exactly where the
+// reference assigns to float / float3.  tri = {v, e1, e2} in fp64 (wave-uniform); dd = the
+// ray direction in fp64.  `float inv_det = 1. / det` is a double division narrowed to float;
+// for a float det that equals the correctly rounded fp32 quotient (1/det cannot lie within
+// 2^-49 of a float midpoint), so the fp32 divide is used.
+__device__ __forceinline__ bool tri_intersect(const double ddx, const double ddy, const double ddz,
+                                              const float ox, const float oy, const float oz,
+                                              const double* __restrict__ tri, float* t_out)
+{
+    const double vx = tri[0], vy = tri[1], vz = tri[2];
+    const double e1x = tri[3], e1y = tri[4], e1z = tri[5];
+    const double e2x = tri[6], e2y = tri[7], e2z = tri[8];
+    const float Px = float(ddy * e2z - ddz * e2y);
+    const float Py = float(ddz * e2x - ddx * e2z);
+    const float Pz = float(ddx * e2y - ddy * e2x);
+    const float det = float((e1x * double(Px) + e1y * double(Py)) + e1z * double(Pz));
+    bool reject = det < 1E-14f;
+    const float inv_det = 1.0f / det;
+    const float OVx = ox - float(vx), OVy = oy - float(vy), OVz = oz - float(vz);
+    const double dOVx = OVx, dOVy = OVy, dOVz = OVz;
+    const float u = float(((dOVx * double(Px) + dOVy * double(Py)) + dOVz * double(Pz)) * double(inv_det));
+    reject = reject || (u < 0.f || u > 1.f);
+    const float Qx = float(dOVy * e1z - dOVz * e1y);
+    const float Qy = float(dOVz * e1x - dOVx * e1z);
+    const float Qz = float(dOVx * e1y - dOVy * e1x);
+    const float v = float(((ddx * double(Qx) + ddy * double(Qy)) + ddz * double(Qz)) * double(inv_det));
+    reject = reject || (v < 0.f || u + v > 1.f);
+    *t_out = float(((e2x * double(Qx) + e2y * double(Qy)) + e2z * double(Qz)) * double(inv_det));
+    return !reject;
 }
 
 // Primitive range of every node: a node's leaves are consecutive (nodes.h:27-28) and so are
@@ -427,7 +498,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
 
     // Axis-aligned packet?  (wave-uniform; tail lanes replicate a valid ray)
     int axis = -1;
-    if (MODE != MODE_HITS) {
+    if (MODE != MODE_HITS && MODE != MODE_TRI) {
         const unsigned long long all = ~0ull;
         const bool zx = dx == 0.f, zy = dy == 0.f, zz = dz == 0.f;
         if (__builtin_amdgcn_ballot_w64(zy && zz && fabsf(dx) == 1.f) == all) axis = 0;
@@ -444,6 +515,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     int count = 0;
     float sum = 0.f;
     int write_at = 0;
+    // MODE_TRI: RayEntry_tri (tris_trace.cuh:63-73): closest index -1, t_min = length (1 + eps)
+    int tri_data = -1;
+    float tri_tmin = len * (1.f + 0.000001f);
+    const double ddx = dx, ddy = dy, ddz = dz;
     if (MODE == MODE_HITS) write_at = a.offsets[ray_index];
     uint32_t st_nodes = 0, st_leaves = 0, st_tested = 0;
 
@@ -575,7 +650,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         nxt4 = pa[jn];
                         if (NEED_B) nxtb = pb[jn];
                     }
-                    {
+                    if (MODE == MODE_TRI) {
+                        // RayIntersect_tri + OnHit_tri (tris_trace.cuh:24-61)
+                        float t;
+                        if (tri_intersect(ddx, ddy, ddz, ox, oy, oz, a.T64 + 9 * size_t(leaf.x + j), &t)) {
+                            if (t <= tri_tmin && t >= 1E-14f) {
+                                tri_tmin = t;
+                                tri_data = leaf.x + j;
+                            }
+                        }
+                    } else {
                         const float4 s = cur;
                         float b2, dot_p;
                         if (AX >= 0) {
@@ -631,6 +715,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     if ((overflow || junk < 0) && lane == 0) *a.status = GRACE_STACK_OVERFLOW;
     if (!valid) return;
     if (MODE == MODE_COUNT) a.out_counts[ray_index] = count;
+    if (MODE == MODE_TRI) a.out_counts[ray_index] = tri_data;
     if (MODE == MODE_CUMULATIVE) a.out_sums[ray_index] = sum;
     if (MODE == MODE_STATS) {
         reinterpret_cast<uint4*>(a.stats)[ray_index] =
@@ -639,6 +724,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
 }
 
 int* g_status = nullptr; // one device int, allocated on first use
+bool g_timing = false;   // record HIP events around the traversal kernel itself
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+bool g_ev_valid = false;
 
 grace_status ensure_status(hipStream_t stream)
 {
@@ -664,10 +752,13 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         GRACE_TRY(Workspace::begin(Workspace::aligned((n_spheres + 4) * sizeof(float4))
                                    + Workspace::aligned((n_spheres + 4) * sizeof(float2))
                                    + Workspace::aligned(n_nodes * sizeof(int2))
+                                   + (MODE == MODE_TRI ? Workspace::aligned(72 * (n_spheres + 4)) : 0)
                                    + (reorder ? 2 * Workspace::aligned(n_rays * 4)
                                                 + sort_ws_bytes(n_rays, 4, 0) : 0) + 1024));
         float4* A = Workspace::take<float4>(n_spheres + 4);
         float2* B = need_b ? Workspace::take<float2>(n_spheres + 4) : nullptr;
+        double* T64 = (MODE == MODE_TRI) ? Workspace::take<double>(9 * (n_spheres + 4)) : nullptr;
+        a.T64 = T64;
         int2* node_prims = Workspace::take<int2>(n_nodes);
         node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
             reinterpret_cast<const int4*>(a.nodes), a.leaves, int(n_nodes), node_prims);
@@ -689,8 +780,12 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             GRACE_TRY(sort_pairs_u32_nested(keys, nullptr, n_rays, 0, 0, 30, perm, stream));
             a.perm = perm;
         }
-        trace_prepass_kernel<<<stream_grid(n_spheres + 4, 256), 256, 0, stream>>>(
-            a.spheres, n_spheres, A, B);
+        if (MODE == MODE_TRI)
+            tri_prepass_kernel<<<stream_grid(n_spheres + 4, 256), 256, 0, stream>>>(
+                reinterpret_cast<const float*>(a.spheres), n_spheres, A, T64);
+        else
+            trace_prepass_kernel<<<stream_grid(n_spheres + 4, 256), 256, 0, stream>>>(
+                a.spheres, n_spheres, A, B);
         GRACE_CHECK_LAUNCH();
         a.A = A;
         a.B = B;
@@ -699,8 +794,19 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     a.n_nodes = int(n_nodes);
     a.status = g_status;
     const int n_packets = ceil_div(n_rays, 64);
+    if (g_timing) {
+        if (!g_ev0) {
+            GRACE_TRY_HIP(hipEventCreate(&g_ev0));
+            GRACE_TRY_HIP(hipEventCreate(&g_ev1));
+        }
+        GRACE_TRY_HIP(hipEventRecord(g_ev0, stream));
+    }
     trace_kernel<MODE><<<ceil_div(n_packets, TRACE_BLOCK / 64), TRACE_BLOCK, 0, stream>>>(a);
     GRACE_CHECK_LAUNCH();
+    if (g_timing) {
+        GRACE_TRY_HIP(hipEventRecord(g_ev1, stream));
+        g_ev_valid = true;
+    }
     return GRACE_OK;
 }
 
@@ -762,6 +868,22 @@ grace_status grace_trace_hits_f4(const void* d_rays, size_t n_rays, const float*
     return launch_trace<MODE_HITS>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
 }
 
+grace_status grace_trace_closest_tri(const void* d_rays, size_t n_rays, const float* d_tris,
+                                     size_t n_tris, const int* d_nodes, size_t n_nodes,
+                                     const int* d_leaves, const int* d_root, int* d_closest,
+                                     grace_stream stream)
+{
+    GRACE_REQUIRE(d_closest, "trace_closest_tri: null output");
+    TraceArgs a = {};
+    a.rays = static_cast<const float*>(d_rays);
+    a.spheres = reinterpret_cast<const float4*>(d_tris); // 9 floats per triangle
+    a.nodes = reinterpret_cast<const float4*>(d_nodes);
+    a.leaves = reinterpret_cast<const int4*>(d_leaves);
+    a.root = d_root;
+    a.out_counts = d_closest;
+    return launch_trace<MODE_TRI>(a, n_rays, n_tris, n_nodes, as_stream(stream));
+}
+
 grace_status grace_trace_stats_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
                                   size_t n_spheres, const int* d_nodes, size_t n_nodes,
                                   const int* d_leaves, const int* d_root,
@@ -785,6 +907,22 @@ grace_status grace_hit_integrals_f32(const float* d_b2, const float* d_h, size_t
     if (n == 0) return GRACE_OK;
     hit_integrals_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(d_b2, d_h, n, d_out);
     GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+grace_status grace_trace_enable_timing(int enabled)
+{
+    g_timing = enabled != 0;
+    g_ev_valid = false;
+    return GRACE_OK;
+}
+
+grace_status grace_trace_last_kernel_ms(float* h_ms)
+{
+    GRACE_REQUIRE(h_ms, "null output");
+    GRACE_REQUIRE(g_timing && g_ev_valid, "no timed traversal launch recorded");
+    GRACE_TRY_HIP(hipEventSynchronize(g_ev1));
+    GRACE_TRY_HIP(hipEventElapsedTime(h_ms, g_ev0, g_ev1));
     return GRACE_OK;
 }
 

@@ -250,6 +250,17 @@ def hit_integrals(b2, h):
     return out
 
 
+def enable_kernel_timing(enabled=True):
+    _check(_lib.grace_trace_enable_timing(C.c_int(1 if enabled else 0)))
+
+
+def last_kernel_ms():
+    """Duration of the last traversal kernel alone (HIP events on its stream)."""
+    ms = C.c_float(0)
+    _check(_lib.grace_trace_last_kernel_ms(C.byref(ms)))
+    return ms.value
+
+
 def set_treelet_size(n):
     _check(_lib.grace_trace_set_treelet_size(C.c_int(int(n))))
 
@@ -296,11 +307,82 @@ def trace_sph(rays, spheres, tree):
     return offsets, idx, integrals, dists
 
 
+def trace_with_sentinels_sph(rays, spheres, tree, index_sentinel, integral_sentinel,
+                             distance_sentinel):
+    """trace_sph.cuh:171-241: like trace_sph, but every ray's segment ends with one sentinel
+    slot; returns (ray_offsets, hit_indices, hit_integrals, hit_distances)."""
+    _check_rays(rays)
+    n = len(rays)
+    offsets = torch.empty(n, dtype=torch.int32, device=rays.device)
+    trace_hitcounts_sph(rays, spheres, tree, offsets)
+    total = exclusive_scan(offsets, offsets) + n
+    _check(_lib.grace_add_iota_i32(_ptr(offsets), C.c_size_t(n), _stream()))
+    idx = torch.empty(total, dtype=torch.int32, device=rays.device)
+    integrals = torch.empty(total, dtype=torch.float32, device=rays.device)
+    dists = torch.empty(total, dtype=torch.float32, device=rays.device)
+    bits = lambda f: int(np.float32(f).view(np.uint32))
+    _check(_lib.grace_fill_u32(_ptr(idx), C.c_size_t(total), C.c_uint32(index_sentinel & 0xFFFFFFFF), _stream()))
+    _check(_lib.grace_fill_u32(_ptr(integrals), C.c_size_t(total), C.c_uint32(bits(integral_sentinel)), _stream()))
+    _check(_lib.grace_fill_u32(_ptr(dists), C.c_size_t(total), C.c_uint32(bits(distance_sentinel)), _stream()))
+    _check(_lib.grace_trace_hits_f4(*_trace_args(rays, spheres, tree), _ptr(offsets), _ptr(idx),
+                                    _ptr(integrals), _ptr(dists), _stream()))
+    return offsets, idx, integrals, dists
+
+
 def trace_stats(rays, spheres, tree):
     """Per ray {nodes, leaves, spheres tested, hits} for that ray alone."""
     stats = torch.empty((len(rays), 4), dtype=torch.int32, device=rays.device)
     _check(_lib.grace_trace_stats_f4(*_trace_args(rays, spheres, tree), _ptr(stats), _stream()))
     return stats
+
+
+# ---------------------------------------------------------------------------------------
+# Triangles -- tests/profile_trace_triangle/{tris_tree.cuh,tris_trace.cu}
+# ---------------------------------------------------------------------------------------
+def _tris(t):
+    assert t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 9 and t.is_contiguous()
+    return t
+
+
+def build_tree_tris(tris, tree):
+    """tris_tree.cuh:17-30: centroid bounds, 30-bit keys, stable sort of the triangles, XOR
+    deltas, ALBVH with TriangleAABB.  Sorts tris in place; returns (bots, tops)."""
+    n = len(_tris(tris))
+    bot = (C.c_float * 3)(); top = (C.c_float * 3)()
+    _check(_lib.grace_centroid_bounds_tri(_ptr(tris), C.c_size_t(n), bot, top, _stream()))
+    keys = torch.empty(n, dtype=torch.int32, device=tris.device)
+    _check(_lib.grace_morton_keys30_tri(_ptr(tris), C.c_size_t(n), bot, top, _ptr(keys), _stream()))
+    sort_by_key(keys, tris, 0, 30)
+    deltas = torch.empty(n + 1, dtype=torch.int32, device=tris.device)
+    XOR_deltas_sph(keys, deltas)
+    n_leaves = C.c_size_t(0)
+    _check(_lib.grace_albvh_build_tri_u32(_ptr(tris), C.c_size_t(n), _ptr(deltas),
+                                          C.c_int(tree.max_per_leaf), _ptr(tree.nodes),
+                                          _ptr(tree.leaves), _ptr(tree.root_index),
+                                          C.byref(n_leaves), _stream()))
+    tree.leaves = tree.leaves[: n_leaves.value]
+    tree.nodes = tree.nodes[: n_leaves.value - 1]
+    return np.array(bot, np.float32), np.array(top, np.float32)
+
+
+def trace_closest_tri(rays, tris, tree, closest):
+    """tris_trace.cu:43-62."""
+    _check_rays(rays)
+    assert closest.dtype == torch.int32 and len(closest) == len(rays)
+    _check(_lib.grace_trace_closest_tri(_ptr(rays), C.c_size_t(len(rays)), _ptr(_tris(tris)),
+                                        C.c_size_t(len(tris)), _ptr(tree.nodes),
+                                        C.c_size_t(tree.n_nodes), _ptr(tree.leaves),
+                                        _ptr(tree.root_index), _ptr(closest), _stream()))
+    return closest
+
+
+def pinhole_camera_rays(res_x, res_y, camera, look_at, view_up, fovy, length, device="cuda"):
+    rays = torch.empty((res_x * res_y, RAY_FLOATS), dtype=torch.float32, device=device)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    _check(_lib.grace_rays_pinhole(C.c_int(res_x), C.c_int(res_y), f3(camera), f3(look_at),
+                                   f3(view_up), C.c_float(fovy), C.c_float(length), _ptr(rays),
+                                   _stream()))
+    return rays
 
 
 # ---------------------------------------------------------------------------------------

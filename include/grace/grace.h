@@ -22,6 +22,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -327,6 +328,40 @@ inline void trace_sph(const device_vector<Ray>& d_rays, const device_vector<floa
                                       d_tree.root_index_ptr, d_ray_offsets.data(),
                                       d_hit_indices.data(), d_hit_integrals.data(),
                                       d_hit_distances.data(), nullptr));
+    detail::check(grace_trace_status(nullptr));
+}
+
+// trace_sph.cuh:171-241
+inline void trace_with_sentinels_sph(const device_vector<Ray>& d_rays,
+                                     const device_vector<float4>& d_spheres, const Tree& d_tree,
+                                     device_vector<int>& d_ray_offsets,
+                                     device_vector<int>& d_hit_indices, const int index_sentinel,
+                                     device_vector<float>& d_hit_integrals,
+                                     const float integral_sentinel,
+                                     device_vector<float>& d_hit_distances,
+                                     const float distance_sentinel)
+{
+    const size_t n_rays = d_rays.size();
+    trace_hitcounts_sph(d_rays, d_spheres, d_tree, d_ray_offsets);
+    long long total = 0;
+    detail::check(grace_scan_exclusive_i32(d_ray_offsets.data(), n_rays, d_ray_offsets.data(),
+                                           &total, nullptr));
+    const size_t allocate_size = size_t(total) + n_rays;
+    detail::check(grace_add_iota_i32(d_ray_offsets.data(), n_rays, nullptr));
+    d_hit_indices.resize(allocate_size);
+    d_hit_integrals.resize(allocate_size);
+    d_hit_distances.resize(allocate_size);
+    uint32_t ib, db;
+    std::memcpy(&ib, &integral_sentinel, 4);
+    std::memcpy(&db, &distance_sentinel, 4);
+    detail::check(grace_fill_u32(d_hit_indices.data(), allocate_size, uint32_t(index_sentinel), nullptr));
+    detail::check(grace_fill_u32(d_hit_integrals.data(), allocate_size, ib, nullptr));
+    detail::check(grace_fill_u32(d_hit_distances.data(), allocate_size, db, nullptr));
+    detail::check(grace_trace_hits_f4(d_rays.data(), n_rays, &d_spheres.data()->x, d_spheres.size(),
+                                      &d_tree.nodes.data()->x, d_tree.leaves.size() - 1,
+                                      &d_tree.leaves.data()->x, d_tree.root_index_ptr,
+                                      d_ray_offsets.data(), d_hit_indices.data(),
+                                      d_hit_integrals.data(), d_hit_distances.data(), nullptr));
     detail::check(grace_trace_status(nullptr));
 }
 

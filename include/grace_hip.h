@@ -119,6 +119,29 @@ grace_status grace_albvh_build_f4_u32(const float* d_spheres, size_t n, const ui
                                       int max_per_leaf, int* d_nodes, int* d_leaves,
                                       int* d_root, size_t* h_n_leaves, grace_stream stream);
 
+/* ---- triangle primitives: the alternate-primitive instantiation of the same templates
+ *      (tests/profile_trace_triangle).  Triangle = {v, e1, e2}, 9 floats, 36 B
+ *      (triangle.cuh:11-25). ------------------------------------------------------------- */
+/* compute_centroids + min/max with TriangleCentroid (triangle.cuh:92-102;
+ * include/grace/cuda/kernels/morton.cuh:139-174).  Synchronises. */
+grace_status grace_centroid_bounds_tri(const float* d_tris, size_t n, float* h_bot, float* h_top,
+                                       grace_stream stream);
+/* grace::morton_keys(d_tris, ..., TriangleCentroid()) with 30-bit keys (tris_tree.cuh:27). */
+grace_status grace_morton_keys30_tri(const float* d_tris, size_t n, const float* h_bot,
+                                     const float* h_top, uint32_t* d_keys, grace_stream stream);
+/* grace::build_ALBVH(d_tree, d_tris, d_deltas, TriangleAABB()) with XOR deltas
+ * (tris_tree.cuh:28-29; TriangleAABB triangle.cu:3-35). */
+grace_status grace_albvh_build_tri_u32(const float* d_tris, size_t n, const uint32_t* d_deltas,
+                                       int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                       size_t* h_n_leaves, grace_stream stream);
+/* trace_closest_tri (tris_trace.cu:43-62): RayEntry_tri / RayIntersect_tri / OnHit_tri
+ * (tris_trace.cuh:11-73) over Moeller-Trumbore with back-face culling (triangle.cuh:54-88);
+ * d_closest[ray] = index of the nearest triangle hit, or -1. */
+grace_status grace_trace_closest_tri(const void* d_rays, size_t n_rays, const float* d_tris,
+                                     size_t n_tris, const int* d_nodes, size_t n_nodes,
+                                     const int* d_leaves, const int* d_root, int* d_closest,
+                                     grace_stream stream);
+
 /* ---- traversal: grace::trace_hitcounts_sph / trace_cumulative_sph / trace_sph pass 2
  *      (include/grace/cuda/trace_sph.cuh:58-168) over trace_kernel
  *      (include/grace/cuda/kernels/bintree_trace.cuh:52-197).  n_nodes = n_leaves - 1.
@@ -160,6 +183,12 @@ grace_status grace_hit_integrals_f32(const float* d_b2, const float* d_h, size_t
  * the reference.  Default 1.  Not part of the reference API. */
 grace_status grace_trace_set_ray_reorder(int enabled);
 
+/* Measurement hook: when enabled, HIP events are recorded on the call's stream directly
+ * around the traversal kernel of every trace call (not around its pre-passes);
+ * grace_trace_last_kernel_ms waits for the last one and returns its duration. */
+grace_status grace_trace_enable_timing(int enabled);
+grace_status grace_trace_last_kernel_ms(float* h_ms);
+
 /* Subtrees with at most this many primitives are swept in one culling pass instead of being
  * descended (results per ray unchanged).  0 disables; default 256. */
 grace_status grace_trace_set_treelet_size(int max_primitives);
@@ -183,6 +212,11 @@ grace_status grace_segscan_exclusive_f32(const int* d_segment_offsets, size_t n_
 grace_status grace_segscan_exclusive_f64(const int* d_segment_offsets, size_t n_segments,
                                          const double* d_data, size_t n, double* d_results,
                                          grace_stream stream);
+/* Pieces of trace_with_sentinels_sph (include/grace/cuda/trace_sph.cuh:171-241):
+ * offsets[i] += i (thrust::transform with a counting iterator, :205-208) and the sentinel
+ * fill of the per-hit arrays (:212-214; 32-bit pattern, so int and float sentinels alike). */
+grace_status grace_add_iota_i32(int* d_values, size_t n, grace_stream stream);
+grace_status grace_fill_u32(void* d_values, size_t n, uint32_t bits, grace_stream stream);
 /* detail::multiply_by_weights (include/grace/cuda/kernels/weights.cuh:13-27). */
 grace_status grace_multiply_by_weights_f32(const float* d_unweighted, size_t n,
                                            const float* d_weights, const uint32_t* d_weight_map,
@@ -194,6 +228,10 @@ grace_status grace_multiply_by_weights_f32(const float* d_unweighted, size_t n,
  * (tests/helper/rays.cuh:55-79; kernels/gen_rays.cuh:319-360,667-725). mins4/maxs4 host. */
 grace_status grace_rays_orthogonal_z(int n_side, const float* h_mins4, const float* h_maxs4,
                                      void* d_rays, float* h_area, grace_stream stream);
+/* pinhole_camera_rays (kernels/gen_rays.cuh:362-395,727-789), Real = float; fovy in radians. */
+grace_status grace_rays_pinhole(int res_x, int res_y, const float* h_camera, const float* h_look_at,
+                                const float* h_view_up, float fovy, float length, void* d_rays,
+                                grace_stream stream);
 /* One source, HEALPix nested pixel centres (RayVectorGeneration/src/generateRays.c:57-59). */
 grace_status grace_rays_healpix(int nside, float ox, float oy, float oz, float length,
                                 void* d_rays, grace_stream stream);

@@ -337,7 +337,10 @@ static void prim_aabb(const float* prims, int kind, size_t i, float* bot, float*
             float v0 = t[k], v1 = t[k] + t[3 + k], v2 = t[k] + t[6 + k];
             bot[k] = fminf(v0, fminf(v1, v2));
             top[k] = fmaxf(v0, fmaxf(v1, v2));
-            if (bot[k] == top[k]) { bot[k] -= GO_TRI_AABB_EPS; top[k] += GO_TRI_AABB_EPS; }
+            if (bot[k] == top[k]) { /* triangle.cu:21-35: inflate by eps * |coordinate| */
+                float scale = fabsf(bot[k]);
+                bot[k] -= GO_TRI_AABB_EPS * scale; top[k] += GO_TRI_AABB_EPS * scale;
+            }
         }
     }
 }
@@ -788,5 +791,134 @@ void go_orthogonal_rays_z(int n_side, const float* mins4, const float* maxs4,
         r.oz = cam[2] + (x * 0.f + y * 0.f + 1.f * 0.f);
         r.length = length;
         rays[t] = r;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Triangle primitive path (tests/profile_trace_triangle)                     */
+/* ------------------------------------------------------------------------- */
+
+/* Triangle = {v, e1, e2}, 9 floats (tests/profile_trace_triangle/triangle.cuh:11-25). */
+typedef struct { float v[3], e1[3], e2[3]; } go_tri;
+
+/* TriangleCentroid (triangle.cuh:92-102): v + (1./3.) * (e1 + e2); the scalar binds to
+ * operator*(float, float3) (tests/helper/vector_math.cuh:34-37), so all fp32. */
+static inline void tri_centroid(const go_tri* t, float* c)
+{
+    const float third = (float)(1. / 3.);
+    for (int k = 0; k < 3; ++k) c[k] = t->v[k] + third * (t->e1[k] + t->e2[k]);
+}
+
+void go_tri_centroid_bounds(const go_tri* tris, size_t n, float* bot, float* top)
+{
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (size_t i = 0; i < n; ++i) {
+        float c[3]; tri_centroid(&tris[i], c);
+        for (int k = 0; k < 3; ++k) { if (c[k] < lo[k]) lo[k] = c[k]; if (c[k] > hi[k]) hi[k] = c[k]; }
+    }
+    for (int k = 0; k < 3; ++k) { bot[k] = lo[k]; top[k] = hi[k]; }
+}
+
+/* grace::morton_keys(d_tris, d_keys, TriangleCentroid(), ...) (tris_tree.cuh:27,
+ * kernels/morton.cuh:43-50,107-113) with 30-bit keys. */
+void go_morton_keys30_tri(const go_tri* tris, size_t n, const float* bot, const float* top,
+                          uint32_t* keys)
+{
+    const int span = (1u << 10) - 1;
+    float sx = span / (top[0] - bot[0]), sy = span / (top[1] - bot[1]), sz = span / (top[2] - bot[2]);
+    for (size_t i = 0; i < n; ++i) {
+        float c[3]; tri_centroid(&tris[i], c);
+        keys[i] = go_morton_key30((uint32_t)(sx * (c[0] - bot[0])), (uint32_t)(sy * (c[1] - bot[1])),
+                                  (uint32_t)(sz * (c[2] - bot[2])));
+    }
+}
+
+void go_tri_aabb(const go_tri* t, float* bot, float* top) { prim_aabb((const float*)t, 1, 0, bot, top); }
+
+/* tests/helper/vector_math.cu:27-52: fp64 products and sums, results narrowed to float
+ * where the reference assigns to float3 / float. */
+static inline double tri_dot(const float* a, const float* b)
+{
+    double x = (double)a[0] * b[0], y = (double)a[1] * b[1], z = (double)a[2] * b[2];
+    return x + y + z;
+}
+static inline void tri_cross(const float* a, const float* b, float* r)
+{
+    r[0] = (float)((double)a[1] * b[2] - (double)a[2] * b[1]);
+    r[1] = (float)((double)a[2] * b[0] - (double)a[0] * b[2]);
+    r[2] = (float)((double)a[0] * b[1] - (double)a[1] * b[0]);
+}
+
+#define GO_TRIANGLE_EPSILON 1E-14f
+
+/* Moeller-Trumbore, back faces culled (triangle.cuh:54-88). */
+static inline int tri_intersect(const go_ray* ray, const go_tri* tri, float* t)
+{
+    const float dir[3] = { ray->dx, ray->dy, ray->dz };
+    float P[3]; tri_cross(dir, tri->e2, P);
+    float det = (float)tri_dot(tri->e1, P);
+    if (det < GO_TRIANGLE_EPSILON) return 0;
+    float inv_det = (float)(1. / det);
+    const float OV[3] = { ray->ox - tri->v[0], ray->oy - tri->v[1], ray->oz - tri->v[2] };
+    float u = (float)(tri_dot(OV, P) * inv_det);
+    if (u < 0.f || u > 1.f) return 0;
+    float Q[3]; tri_cross(OV, tri->e1, Q);
+    float v = (float)(tri_dot(dir, Q) * inv_det);
+    if (v < 0.f || u + v > 1.f) return 0;
+    *t = (float)(tri_dot(tri->e2, Q) * inv_det);
+    return 1;
+}
+
+int go_tri_intersect(const go_ray* ray, const go_tri* tri, float* t) { return tri_intersect(ray, tri, t); }
+
+/* trace_closest_tri (tris_trace.cu:43-62) by brute force: RayEntry_tri, RayIntersect_tri,
+ * OnHit_tri (tris_trace.cuh:11-73) applied to every triangle in index order -- what the
+ * packet traversal computes when it is conservative. */
+void go_brute_closest_tri(const go_ray* rays, size_t n_rays, const go_tri* tris, size_t n, int* out,
+                          float* t_out)
+{
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (size_t ri = 0; ri < n_rays; ++ri) {
+        go_ray ray = rays[ri];
+        int data = -1;
+        float t_min = ray.length * (1.f + GO_TRI_AABB_EPS);
+        for (size_t i = 0; i < n; ++i) {
+            float t;
+            if (tri_intersect(&ray, &tris[i], &t) && t <= t_min && t >= GO_TRIANGLE_EPSILON) {
+                t_min = t; data = (int)i;
+            }
+        }
+        out[ri] = data;
+        if (t_out) t_out[ri] = t_min;
+    }
+}
+
+/* pinhole_camera_rays (include/grace/cuda/kernels/gen_rays.cuh:362-395,727-789), Real =
+ * float: basis on the host, image_plane_coord + normalisation per ray.  The reference
+ * normalises with rnorm3d on the device; here 1/sqrt in fp32 (inputs, not parity-bound). */
+void go_pinhole_rays(int res_x, int res_y, const float* cam, const float* look_at, const float* up,
+                     float fovy, float length, go_ray* rays)
+{
+    float vd[3] = { look_at[0] - cam[0], look_at[1] - cam[1], look_at[2] - cam[2] };
+    float c1[3] = { vd[1] * up[2] - vd[2] * up[1], vd[2] * up[0] - vd[0] * up[2], vd[0] * up[1] - vd[1] * up[0] };
+    double N = 1. / sqrt((double)(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]));
+    float v[3] = { (float)(c1[0] * N), (float)(c1[1] * N), (float)(c1[2] * N) };
+    float c2[3] = { v[1] * vd[2] - v[2] * vd[1], v[2] * vd[0] - v[0] * vd[2], v[0] * vd[1] - v[1] * vd[0] };
+    N = 1. / sqrt((double)(c2[0] * c2[0] + c2[1] * c2[1] + c2[2] * c2[2]));
+    float u[3] = { (float)(c2[0] * N), (float)(c2[1] * N), (float)(c2[2] * N) };
+    N = 1. / sqrt((double)(vd[0] * vd[0] + vd[1] * vd[1] + vd[2] * vd[2]));
+    float n[3] = { (float)(vd[0] * N), (float)(vd[1] * N), (float)(vd[2] * N) };
+    float pre = (float)(1. / tan(fovy / 2.));
+    for (int k = 0; k < 3; ++k) n[k] *= pre;
+    float aspect = (float)res_x / res_y;
+    for (int tid = 0; tid < res_x * res_y; ++tid) {
+        int i = tid % res_x, j = tid / res_x;
+        float x = (2 * ((i + 0.5f) / res_x) - 1) * aspect;
+        float y = 1 - 2 * ((j + 0.5f) / res_y);
+        float d[3];
+        for (int k = 0; k < 3; ++k) d[k] = x * v[k] + y * u[k] + 1.f * n[k];
+        float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        go_ray r = { d[0] * inv, d[1] * inv, d[2] * inv, cam[0], cam[1], cam[2], length };
+        rays[tid] = r;
     }
 }

@@ -277,3 +277,43 @@ def ray_dir_keys(rays):
     f.restype = C.c_uint32
     f.argtypes = [C.c_void_p]
     return np.array([f(rays[i:i + 1].ctypes.data) for i in range(len(rays))], np.uint32)
+
+
+# -- triangles (tests/profile_trace_triangle) -------------------------------------------
+
+def _tris(t):
+    t = np.ascontiguousarray(t, np.float32)
+    assert t.ndim == 2 and t.shape[1] == 9
+    return t
+
+
+def tri_centroid_bounds(tris):
+    tris = _tris(tris)
+    b = np.empty(3, np.float32); t = np.empty(3, np.float32)
+    lib().go_tri_centroid_bounds(_p(tris), C.c_size_t(len(tris)), _p(b), _p(t))
+    return b, t
+
+
+def morton_keys30_tri(tris, bot, top):
+    tris = _tris(tris)
+    keys = np.empty(len(tris), np.uint32)
+    b = np.asarray(bot, np.float32); t = np.asarray(top, np.float32)
+    lib().go_morton_keys30_tri(_p(tris), C.c_size_t(len(tris)), _p(b), _p(t), _p(keys))
+    return keys
+
+
+def brute_closest_tri(rays, tris):
+    rays = _rays(rays); tris = _tris(tris)
+    out = np.empty(len(rays), np.int32); t = np.empty(len(rays), np.float32)
+    lib().go_brute_closest_tri(_p(rays), C.c_size_t(len(rays)), _p(tris), C.c_size_t(len(tris)),
+                               _p(out), _p(t))
+    return out, t
+
+
+def pinhole_rays(res_x, res_y, cam, look_at, up, fovy, length):
+    rays = np.empty(res_x * res_y, RAY_DTYPE)
+    f = lambda v: np.asarray(v, np.float32)
+    a, b, c = f(cam), f(look_at), f(up)
+    lib().go_pinhole_rays(C.c_int(res_x), C.c_int(res_y), _p(a), _p(b), _p(c), C.c_float(fovy),
+                          C.c_float(length), _p(rays))
+    return rays

@@ -101,6 +101,26 @@ def test_trace_sph_hits(gh, oracle, cuda, n, n_rays, mpl):
     assert np.allclose(out.cpu().numpy(), oracle.segscan(ro, rw), rtol=2e-6, atol=1e-30)
 
 
+def test_trace_with_sentinels(gh, oracle, cuda):
+    s = oracle.random_real4(20000, (0, 0, 0, 0), (1, 1, 1, 0.08))
+    d, tree = _build(gh, cuda, s, 16)
+    rays = gh.uniform_random_rays(256, (0.5, 0.5, 0.5), 2.0, seed=9, device=cuda)
+    offs, idx, integ, dist = gh.trace_with_sentinels_sph(rays, d, tree, -7, -1.5, 1e30)
+    ro, ri, rw, rd = oracle.brute_hits(rays.cpu().numpy(), d.cpu().numpy())
+    counts = np.diff(np.concatenate([ro, [len(ri)]]))
+    so = ro + np.arange(len(ro), dtype=np.int32)            # trace_sph.cuh:205-208
+    assert np.array_equal(offs.cpu().numpy(), so)
+    gi = idx.cpu().numpy(); gw = integ.cpu().numpy(); gd = dist.cpu().numpy()
+    assert len(gi) == len(ri) + len(ro)
+    for r in (0, 1, 17, 255):
+        a, c = so[r], counts[r]
+        assert np.array_equal(gi[a:a + c], ri[ro[r]:ro[r] + c])
+        assert np.array_equal(gw[a:a + c].view(np.uint32), rw[ro[r]:ro[r] + c].view(np.uint32))
+        assert gi[a + c] == -7 and gw[a + c] == np.float32(-1.5) and gd[a + c] == np.float32(1e30)
+    sent = so + counts
+    assert np.all(gi[sent] == -7)
+
+
 # ---- scans ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("count,max_seg", [(1, 1), (1000, 5), (10000, 3), (100000, 64),
                                            (1 << 20, 2000), (3000000, 100000)])
