@@ -405,6 +405,14 @@ def exclusive_segmented_scan(segment_offsets, data, results):
     return results
 
 
+def sort_by_distance(hit_distances, ray_offsets, hit_indices, hit_data):
+    """sort.cuh:100-131: per-ray sort by distance; indices and data follow."""
+    _check(_lib.grace_sort_by_distance_f32(_ptr(hit_distances), _ptr(ray_offsets),
+                                           C.c_size_t(len(ray_offsets)),
+                                           C.c_size_t(len(hit_distances)), _ptr(hit_indices),
+                                           _ptr(hit_data), _stream()))
+
+
 def weighted_exclusive_segmented_scan(to_sum, weights, weight_map, segment_offsets, out):
     """scan.cuh:43-58."""
     weighted = torch.empty_like(to_sum)

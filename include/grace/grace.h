@@ -383,6 +383,16 @@ inline void exclusive_segmented_scan(const device_vector<int>& d_segment_offsets
                                               nullptr));
 }
 
+// include/grace/cuda/sort.cuh:100-131
+inline void sort_by_distance(device_vector<float>& d_hit_distances,
+                             const device_vector<int>& d_ray_offsets,
+                             device_vector<int>& d_hit_indices, device_vector<float>& d_hit_data)
+{
+    detail::check(grace_sort_by_distance_f32(d_hit_distances.data(), d_ray_offsets.data(),
+                                             d_ray_offsets.size(), d_hit_distances.size(),
+                                             d_hit_indices.data(), d_hit_data.data(), nullptr));
+}
+
 // util/extrema.cuh min_vec4 / max_vec4 as used by tests/project_gadget/project_gadget.cu:66-68
 inline void min_max_vec4(const device_vector<float4>& d_v, float4* mins, float4* maxs)
 {

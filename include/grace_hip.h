@@ -222,6 +222,14 @@ grace_status grace_multiply_by_weights_f32(const float* d_unweighted, size_t n,
                                            const float* d_weights, const uint32_t* d_weight_map,
                                            float* d_weighted, grace_stream stream);
 
+/* ---- per-ray sort of hits by distance: grace::sort_by_distance
+ *      (include/grace/cuda/sort.cuh:100-131): within each ray's segment distances become
+ *      non-decreasing (equal distances keep their order); hit_indices and hit_data (either
+ *      may be NULL) are permuted by the same map. ---------------------------------------- */
+grace_status grace_sort_by_distance_f32(float* d_distances, const int* d_ray_offsets,
+                                        size_t n_rays, size_t n_hits, int* d_hit_indices,
+                                        float* d_hit_data, grace_stream stream);
+
 /* ---- ray inputs (deterministic generators; the reference's cuRAND streams are
  *      device-specific by its own account, include/grace/cuda/kernels/gen_rays.cuh:21-24) */
 /* orthographic_projection_rays specialised as orthogonal_rays_z

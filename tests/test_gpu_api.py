@@ -121,6 +121,44 @@ def test_trace_with_sentinels(gh, oracle, cuda):
     assert np.all(gi[sent] == -7)
 
 
+def test_sort_by_distance(gh, oracle, cuda):
+    """tests/distance_sort/distance_sort.cu:22-79,125-130: after trace_sph + sort_by_distance
+    distances are non-decreasing within each ray and none is negative; here also equal to a
+    stable per-segment host sort, with indices and integrals following."""
+    s = oracle.random_real4(30000, (0, 0, 0, 0), (1, 1, 1, 0.08))
+    d, tree = _build(gh, cuda, s, 32)
+    rays = gh.uniform_random_rays(640, (0.5, 0.5, 0.5), 2.0, seed=21, device=cuda)
+    offs, idx, integ, dist = gh.trace_sph(rays, d, tree)
+    o = offs.cpu().numpy(); i0 = idx.cpu().numpy(); w0 = integ.cpu().numpy(); d0 = dist.cpu().numpy()
+    gh.sort_by_distance(dist, offs, idx, integ)
+    i1 = idx.cpu().numpy(); w1 = integ.cpu().numpy(); d1 = dist.cpu().numpy()
+    assert np.all(d1 >= 0)
+    ends = np.concatenate([o[1:], [len(d0)]])
+    for r in range(len(o)):
+        a, b = o[r], ends[r]
+        order = np.argsort(d0[a:b], kind="stable")
+        assert np.array_equal(d1[a:b].view(np.uint32), d0[a:b][order].view(np.uint32))
+        assert np.array_equal(i1[a:b], i0[a:b][order])
+        assert np.array_equal(w1[a:b].view(np.uint32), w0[a:b][order].view(np.uint32))
+        assert np.all(np.diff(d1[a:b]) >= 0)
+
+
+def test_sort_by_distance_random_segments(gh, cuda):
+    rng = np.random.default_rng(4)
+    sizes = rng.integers(0, 300, 5000); sizes[::9] = 0
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
+    n = int(sizes.sum())
+    dist = rng.integers(0, 50, n).astype(np.float32) * 0.25     # many ties
+    idx = np.arange(n, dtype=np.int32); data = rng.standard_normal(n).astype(np.float32)
+    dd = _dev(dist, cuda); di = _dev(idx, cuda); dw = _dev(data, cuda)
+    gh.sort_by_distance(dd, _dev(offs, cuda), di, dw)
+    seg = np.repeat(np.arange(len(sizes)), sizes)
+    order = np.lexsort((np.arange(n), dist, seg))                 # stable within segments
+    assert np.array_equal(dd.cpu().numpy(), dist[order])
+    assert np.array_equal(di.cpu().numpy(), idx[order])
+    assert np.array_equal(dw.cpu().numpy(), data[order])
+
+
 # ---- scans ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("count,max_seg", [(1, 1), (1000, 5), (10000, 3), (100000, 64),
                                            (1 << 20, 2000), (3000000, 100000)])
