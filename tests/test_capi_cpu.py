@@ -122,3 +122,26 @@ def test_ray_sharding_and_gather_under_gloo(n_rays):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_gadget_roundtrip_python_and_cpp(tmp_path):
+    """Synthetic Gadget-2 file (layout of tests/helper/read_gadget.cuh): Python writer ->
+    Python reader and the C++ header reader (with and without a MASS block)."""
+    sys.path.insert(0, os.path.join(ROOT, "grace-devel_amd"))
+    from grace_hip import gadget
+    rng = np.random.default_rng(3)
+    pos = rng.random((4096, 3), dtype=np.float32); h = (0.01 + 0.02 * rng.random(4096)).astype(np.float32)
+    exe = tmp_path / "rg"
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "read_gadget_check.cpp"), "-o", str(exe),
+                           "-L" + os.path.dirname(LIB), "-lgrace_hip", "-Wl,-rpath," + os.path.dirname(LIB)])
+    for in_header in (True, False):
+        fname = str(tmp_path / ("snap_%d" % in_header))
+        gadget.write_gadget(fname, pos, h, masses_in_header=in_header)
+        s = gadget.read_gadget(fname)
+        assert np.array_equal(s[:, :3], pos) and np.array_equal(s[:, 3], h)
+        out = subprocess.check_output([str(exe), fname], text=True).split()
+        assert int(out[0]) == 4096
+        sums = [float(x) for x in out[1:5]]
+        ref = [float(pos[:, k].astype(np.float64).sum()) for k in range(3)] + [float(h.astype(np.float64).sum())]
+        assert np.allclose(sums, ref, rtol=1e-12)
