@@ -121,9 +121,45 @@ __device__ __forceinline__ void triangle_box(const float* __restrict__ t, float*
 
 enum { PRIM_SPHERE = 0, PRIM_TRIANGLE = 1 };
 
-template <typename D, int PRIM>
-__global__ __launch_bounds__(256) void nodes_climb_kernel(const float4* __restrict__ spheres,
-                                                          const int4* __restrict__ leaves,
+// Leaf AABBs (albvh.cuh:402-424): eight lanes per leaf stride over its primitives, so a
+// wave reads eight runs of consecutive primitives (128 B each for spheres), then an
+// 8-lane shuffle reduction; min/max only, so the boxes are exactly the reference's.
+template <int PRIM>
+__global__ __launch_bounds__(256) void leaf_boxes_kernel(const float4* __restrict__ prims,
+                                                         const int4* __restrict__ leaves,
+                                                         int n_leaves, float* __restrict__ boxes)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = t >> 3, sub = t & 7;
+    float bot[3] = { INFINITY, INFINITY, INFINITY };
+    float top[3] = { -INFINITY, -INFINITY, -INFINITY };
+    if (k < n_leaves) {
+        const int4 leaf = leaves[k];
+        for (int i = sub; i < leaf.y; i += 8) {
+            float b[3], tp[3];
+            if (PRIM == PRIM_SPHERE) sphere_box(prims[leaf.x + i], b, tp);
+            else triangle_box(reinterpret_cast<const float*>(prims) + 9 * size_t(leaf.x + i), b, tp);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                bot[c] = fminf(bot[c], b[c]);
+                top[c] = fmaxf(top[c], tp[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            bot[c] = fminf(bot[c], __shfl_xor(bot[c], off));
+            top[c] = fmaxf(top[c], __shfl_xor(top[c], off));
+        }
+    }
+    if (k < n_leaves && sub < 6)
+        boxes[6 * size_t(k) + sub] = sub < 3 ? bot[sub] : top[sub - 3];
+}
+
+template <typename D>
+__global__ __launch_bounds__(256) void nodes_climb_kernel(const float* __restrict__ boxes,
                                                           int n_leaves,
                                                           const D* __restrict__ lds, int* nodes,
                                                           uint32_t* arrivals, int* root)
@@ -131,19 +167,11 @@ __global__ __launch_bounds__(256) void nodes_climb_kernel(const float4* __restri
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_leaves) return;
     const int n_nodes = n_leaves - 1;
-    const int4 leaf = leaves[k];
-
-    float bot[3] = { INFINITY, INFINITY, INFINITY };
-    float top[3] = { -INFINITY, -INFINITY, -INFINITY };
-    for (int i = 0; i < leaf.y; ++i) {
-        float b[3], t[3];
-        if (PRIM == PRIM_SPHERE) sphere_box(spheres[leaf.x + i], b, t);
-        else triangle_box(reinterpret_cast<const float*>(spheres) + 9 * size_t(leaf.x + i), b, t);
+    float bot[3], top[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            bot[c] = fminf(bot[c], b[c]);
-            top[c] = fmaxf(top[c], t[c]);
-        }
+    for (int c = 0; c < 3; ++c) {
+        bot[c] = boxes[6 * size_t(k) + c];
+        top[c] = boxes[6 * size_t(k) + 3 + c];
     }
 
     int gl = k, gr = k, cur = n_nodes + k;
@@ -207,7 +235,8 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
     const int ni = int(n);
 
     const size_t ws = 3 * Workspace::aligned(n * 4) + Workspace::aligned(scan_ws_count(n) * 4)
-        + Workspace::aligned((n + 1) * sizeof(D)) + Workspace::aligned(n * 4) + 1024;
+        + Workspace::aligned((n + 1) * sizeof(D)) + Workspace::aligned(n * 4)
+        + Workspace::aligned(n * 24) + 1024;
     GRACE_TRY(Workspace::begin(ws));
     uint32_t* flags = Workspace::take<uint32_t>(n);
     uint32_t* counts = Workspace::take<uint32_t>(n);
@@ -216,6 +245,7 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
     D* leaf_ds = Workspace::take<D>(n + 1);
     uint32_t* arrivals = Workspace::take<uint32_t>(n);
     uint32_t* d_total = Workspace::take<uint32_t>(1);
+    float* boxes = Workspace::take<float>(6 * n);
 
     const int grid = ceil_div(n, 256);
     leaf_heads_kernel<D><<<grid, 256, 0, stream>>>(d_deltas, ni, mpl, flags, counts);
@@ -233,9 +263,12 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
                          "build_ALBVH: fewer than two leaves (NaN deltas?)");
 
     GRACE_TRY_HIP(hipMemsetAsync(arrivals, 0, size_t(n_leaves) * 4, stream));
-    nodes_climb_kernel<D, PRIM><<<ceil_div(n_leaves, 256), 256, 0, stream>>>(
+    leaf_boxes_kernel<PRIM><<<ceil_div(size_t(n_leaves) * 8, 256), 256, 0, stream>>>(
         reinterpret_cast<const float4*>(d_spheres), reinterpret_cast<const int4*>(d_leaves),
-        int(n_leaves), leaf_ds, d_nodes, arrivals, d_root);
+        int(n_leaves), boxes);
+    GRACE_CHECK_LAUNCH();
+    nodes_climb_kernel<D><<<ceil_div(n_leaves, 256), 256, 0, stream>>>(
+        boxes, int(n_leaves), leaf_ds, d_nodes, arrivals, d_root);
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
 }
