@@ -53,6 +53,11 @@
 //     values of the general expression (a zero dot_p may differ in sign, which no comparison
 //     sees; the per-hit `distances` output keeps the general form).  10 instead of 22 vector
 //     instructions per candidate sphere;
+//   * LDS-staged candidate tiles: the 64 candidates of a culling round are written once to the
+//     wave's LDS tile; survivors are broadcast-read from it into VGPRs one survivor ahead.
+//     That keeps scalar-memory round trips and their address arithmetic out of the inner
+//     loop, lets the sphere test run on VGPR operands (2.6 instead of 4.3 cycles per
+//     instruction on gfx950) and decouples the table lookup's LDS wait from prefetches;
 //   * packets are dealt to workgroups so that the workgroups sharing an XCD (blockIdx % 8)
 //     walk a contiguous range of packets: neighbouring packets touch the same subtree and
 //     each XCD's 4 MiB L2 keeps it.
@@ -459,6 +464,11 @@ template <int MODE>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
 {
     __shared__ double2 s_lut[N_TABLE];
+    // Per-wave tile of the candidates of the current culling round (MODE_TRI keeps its
+    // fp64 triangles on the scalar path).
+    constexpr bool LDS_TILE = (MODE != MODE_TRI);
+    __shared__ float4 s_tileA[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 64 : 1];
+    __shared__ float2 s_tileB[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 64 : 1];
     if (MODE == MODE_CUMULATIVE || MODE == MODE_HITS) {
         if (threadIdx.x < N_TABLE) {
             const double y0 = c_kernel_table[threadIdx.x];
@@ -628,27 +638,45 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                 const int m = min(64, leaf.y - base);
                 // Lane j: can ANY ray of the beam come within h of sphere j?
                 const float4 mine = pa[base + (lane < m ? lane : 0)];
+                float2 mineb = make_float2(0.f, 0.f);
+                if (LDS_TILE && NEED_B) mineb = pb[base + (lane < m ? lane : 0)];
                 const bool keep = lane < m && beam_may_hit(mine, beam);
                 unsigned long long todo = __builtin_amdgcn_ballot_w64(keep);
 #ifdef GRACE_PACKET_STATS
                 if (MODE == MODE_STATS) { st_leaves += 1; st_tested += __builtin_popcountll(todo); }
 #endif
                 if (todo == 0ull) continue;
+                const int wv = threadIdx.x >> 6;
+                if (LDS_TILE) {
+                    // Stage the round's candidates; survivors are then broadcast-read from LDS
+                    // into VGPRs (in-order LDS returns, no scalar-load round trips, VGPR operands).
+                    s_tileA[wv][lane] = mine;
+                    if (NEED_B) s_tileB[wv][lane] = mineb;
+                }
                 int j = base + __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                float4 cur = pa[j];
+                float4 cur;
                 float2 curb = make_float2(0.f, 0.f);
-                if (NEED_B) curb = pb[j];
+                if (LDS_TILE) {
+                    cur = s_tileA[wv][j - base];
+                    if (NEED_B) curb = s_tileB[wv][j - base];
+                } else {
+                    cur = pa[j];
+                }
                 for (;;) {
                     const bool more = todo != 0ull;
                     int jn = 0;
                     float4 nxt4 = cur;
                     float2 nxtb = curb;
-                    if (more) { // issue the next survivor's scalar loads before the math
+                    if (more) { // issue the next survivor's loads before the math
                         jn = base + __builtin_ctzll(todo);
                         todo &= todo - 1ull;
-                        nxt4 = pa[jn];
-                        if (NEED_B) nxtb = pb[jn];
+                        if (LDS_TILE) {
+                            nxt4 = s_tileA[wv][jn - base];
+                            if (NEED_B) nxtb = s_tileB[wv][jn - base];
+                        } else {
+                            nxt4 = pa[jn];
+                        }
                     }
                     if (MODE == MODE_TRI) {
                         // RayIntersect_tri + OnHit_tri (tris_trace.cuh:24-61)
