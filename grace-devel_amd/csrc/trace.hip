@@ -634,12 +634,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             const float4* pa = a.A + leaf.x;
             const float2* pb = a.B + leaf.x;
             constexpr bool NEED_B = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
+            // The round's 64 candidates are fetched one round ahead (vector loads, 16 B/lane,
+            // coalesced) so that their latency hides behind the previous round's survivors.
+            float4 mine_next = pa[lane < leaf.y ? lane : 0];
+            float2 mineb_next = make_float2(0.f, 0.f);
+            if (LDS_TILE && NEED_B) mineb_next = pb[lane < leaf.y ? lane : 0];
             for (int base = 0; base < leaf.y; base += 64) {
                 const int m = min(64, leaf.y - base);
                 // Lane j: can ANY ray of the beam come within h of sphere j?
-                const float4 mine = pa[base + (lane < m ? lane : 0)];
-                float2 mineb = make_float2(0.f, 0.f);
-                if (LDS_TILE && NEED_B) mineb = pb[base + (lane < m ? lane : 0)];
+                const float4 mine = mine_next;
+                const float2 mineb = mineb_next;
+                if (base + 64 < leaf.y) {
+                    const int nj = base + 64 + lane;
+                    mine_next = pa[nj < leaf.y ? nj : base + 64];
+                    if (LDS_TILE && NEED_B) mineb_next = pb[nj < leaf.y ? nj : base + 64];
+                }
                 const bool keep = lane < m && beam_may_hit(mine, beam);
                 unsigned long long todo = __builtin_amdgcn_ballot_w64(keep);
 #ifdef GRACE_PACKET_STATS
