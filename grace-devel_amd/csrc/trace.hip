@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void hit_integrals_kernel(const float* __restr
 }
 
 bool g_ray_reorder = true;
-int g_treelet = 256;
+int g_treelet = -1; // -1: chosen per call from the packet count (512 on a full GPU, else 256)
 
 // Bounding boxes of the packet's origins and directions (wave-uniform, SGPRs).
 struct Beam {
@@ -801,7 +801,11 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             reinterpret_cast<const int4*>(a.nodes), a.leaves, int(n_nodes), node_prims);
         GRACE_CHECK_LAUNCH();
         a.node_prims = node_prims;
-        a.treelet = (MODE == MODE_STATS) ? 0 : g_treelet;
+        // Wider sweeps pay off once every SIMD holds several packets; with few packets the walk
+        // is latency-bound and shorter sweeps win (measured: 10^7 spheres / 1024^2 rays vs
+        // 10^6 spheres / 10^5 rays).
+        const int auto_treelet = ceil_div(n_rays, 64) >= 4096 ? 512 : 256;
+        a.treelet = (MODE == MODE_STATS) ? 0 : (g_treelet < 0 ? auto_treelet : g_treelet);
         if (reorder) {
             uint32_t* ext = Workspace::take<uint32_t>(12);
             uint32_t* keys = Workspace::take<uint32_t>(n_rays);
@@ -965,7 +969,7 @@ grace_status grace_trace_last_kernel_ms(float* h_ms)
 
 grace_status grace_trace_set_treelet_size(int max_primitives)
 {
-    GRACE_REQUIRE(max_primitives >= 0, "treelet size must be >= 0");
+    GRACE_REQUIRE(max_primitives >= -1, "treelet size must be >= 0 (or -1 for automatic)");
     g_treelet = max_primitives;
     return GRACE_OK;
 }

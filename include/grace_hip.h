@@ -190,7 +190,8 @@ grace_status grace_trace_enable_timing(int enabled);
 grace_status grace_trace_last_kernel_ms(float* h_ms);
 
 /* Subtrees with at most this many primitives are swept in one culling pass instead of being
- * descended (results per ray unchanged).  0 disables; default 256. */
+ * descended (results per ray unchanged).  0 disables; -1 (default) picks 512 when the call
+ * has >= 4096 packets of 64 rays, else 256. */
 grace_status grace_trace_set_treelet_size(int max_primitives);
 
 /* Reads (and clears) the traversal status word: GRACE_STACK_OVERFLOW if any packet ran out
