@@ -374,3 +374,19 @@ def test_config3_integrate_gadget(gh, oracle, cuda, tmp_path):
     pout = torch.empty(len(prays), dtype=torch.float32, device=cuda)
     gh.trace_cumulative_sph(prays, d, tree, pout)
     assert abs(1.0 - float(pout.double().sum()) * area / n) < 5e-4
+
+
+def test_generic_functor_trace_program(tmp_path):
+    """include/grace/hip/trace.hpp (the functor-parameterised kernel for custom primitives /
+    payloads) built with hipcc: reference-style functor compositions == the built-in kernels
+    (hit counts exact, sums bit for bit) and a user-defined functor == a host loop."""
+    lib = os.path.join(ROOT, "grace-devel_amd", "lib")
+    exe = tmp_path / "generic_trace"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17",
+                           "-ffp-contract=off", "-w", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "generic_trace.hip"), "-o", str(exe),
+                           "-L" + lib, "-lgrace_hip", "-L" + os.path.join(ROOT, "oracle"),
+                           "-lgrace_oracle", "-Wl,-rpath," + lib,
+                           "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
