@@ -390,3 +390,30 @@ def test_generic_functor_trace_program(tmp_path):
                            "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_project_gadget_program(tmp_path):
+    """tests/cpp/project_gadget.cpp (mirror of tests/project_gadget): reads a Gadget file
+    written by the Python writer, projects it, writes a valid 24-bit BMP."""
+    from grace_hip import gadget
+    lib = os.path.join(ROOT, "grace-devel_amd", "lib")
+    exe = tmp_path / "project_gadget"
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "project_gadget.cpp"), "-o", str(exe),
+                           "-L" + lib, "-lgrace_hip", "-Wl,-rpath," + lib])
+    rng = np.random.default_rng(8)
+    n = 100000
+    pos = rng.random((n, 3), dtype=np.float32)
+    h = np.full(n, (3 * 48 / (4 * np.pi * n)) ** (1 / 3), np.float32)
+    snap = str(tmp_path / "snap"); bmp = str(tmp_path / "density.bmp")
+    gadget.write_gadget(snap, pos, h)
+    r = subprocess.run([str(exe), "2048", "32", snap, bmp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Number of particles:     100000" in r.stdout and "Number of rays per side: 256" in r.stdout
+    mean = float([l for l in r.stdout.splitlines() if l.startswith("Mean output")][0].split()[2])
+    assert abs(mean / n - 1.0) < 0.05          # unit box, unit masses: mean column density = N
+    raw = open(bmp, "rb").read()
+    assert raw[:2] == b"BM" and len(raw) == 54 + 256 * 256 * 3
+    assert int.from_bytes(raw[18:22], "little") == 256 and raw[28] == 24
+    px = np.frombuffer(raw[54:], np.uint8)
+    assert px.max() > 100 and px.min() < px.max()
