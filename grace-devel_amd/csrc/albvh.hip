@@ -19,11 +19,14 @@
 //   2. scan         : leaf index = exclusive scan of the head flags (scan.hip).
 //   3. write_leaves : compact leaf records + per-leaf deltas (fuses the reference's
 //                     remove_if + copy_leaf_deltas_kernel, albvh.cuh:51-74,826-846).
-//   4. nodes_climb  : ONE bottom-up pass over the leaves (one thread per leaf); the second
-//                     thread to reach a node (agent-scope atomic counter) carries the union
-//                     box upward.  Visibility across CUs/XCDs: release fence before the
-//                     counter, acquire fence after it.
-// Four launches + one scan instead of ~5 launches per level.  Traffic is HBM-bound and
+//   4. leaf_boxes   : leaf AABBs, eight lanes per leaf (coalesced primitive reads).
+//   5. pyramids     : 32-ary maxima of the leaf deltas and 32-ary unions of the leaf boxes
+//                     (log32 n tiny launches).
+//   6. nodes_direct : one thread per node finds its leaf range by nearest-greater search on
+//                     the maxima pyramid, its two child boxes by range unions on the box
+//                     pyramid, and plugs itself into its parent; one thread per leaf does the
+//                     latter.  No atomics, no fences, every word written exactly once.
+// A handful of launches + one scan instead of ~5 launches per level.  Traffic is HBM-bound and
 // small: deltas 8 B, flags/counts 12 B, sphere 16 B per primitive, 64 B per node.
 #include "common.hpp"
 
@@ -158,65 +161,178 @@ __global__ __launch_bounds__(256) void leaf_boxes_kernel(const float4* __restric
         boxes[6 * size_t(k) + sub] = sub < 3 ? bot[sub] : top[sub - 3];
 }
 
-template <typename D>
-__global__ __launch_bounds__(256) void nodes_climb_kernel(const float* __restrict__ boxes,
-                                                          int n_leaves,
-                                                          const D* __restrict__ lds, int* nodes,
-                                                          uint32_t* arrivals, int* root)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_leaves) return;
-    const int n_nodes = n_leaves - 1;
-    float bot[3], top[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        bot[c] = boxes[6 * size_t(k) + c];
-        top[c] = boxes[6 * size_t(k) + 3 + c];
-    }
+// ---- node stage without any inter-thread hand-off ------------------------------------------
+// Node j (between leaves j and j+1) owns the leaves [first, last] bounded by its nearest
+// "greater" neighbours in the order (delta, -index):
+//   first - 1 = the nearest i < j with !(d(i) < d(j)),   last = the nearest i > j with d(j) < d(i)
+// (-1 and n_leaves - 1, the sentinels, if there is none).  Both predicates are threshold tests
+// on d, so block maxima of d (a 32-ary pyramid) locate them in O(32 log32 n) steps; the child
+// boxes are range unions of leaf boxes, answered by a second 32-ary pyramid of box unions
+// (min/max only: the same values as the reference's child-to-parent propagation,
+// albvh.cuh:387-400).  Each node then writes its own record and plugs its index into its
+// parent's child slot; each leaf does the same.  Every word of the node array has exactly one
+// writer: no atomics, no fences, bit-reproducible.
+constexpr int PYR = 32;
+constexpr int PYR_SHIFT = 5;
+constexpr int PYR_MAX_LEVELS = 8;
 
-    int gl = k, gr = k, cur = n_nodes + k;
-    for (;;) {
-        if (gl == 0 && gr == n_leaves - 1) { *root = cur; break; }
-        const bool right_child = lds[gl] < lds[gr + 1]; // delta(gl-1) < delta(gr)
-        const int p = right_child ? gl - 1 : gr;
-        int* np = nodes + 16 * size_t(p);
+template <typename D>
+struct MaxPyramid {
+    const D* level[PYR_MAX_LEVELS]; // level[0][j] = d(j), j in [0, n_nodes); level[k+1][b] = max of 32
+    int size[PYR_MAX_LEVELS];
+    int levels;
+};
+
+struct BoxPyramid {
+    const float* level[PYR_MAX_LEVELS]; // 6 floats per entry {bot xyz, top xyz}
+    int size[PYR_MAX_LEVELS];
+    int levels;
+};
+
+template <typename D>
+__global__ __launch_bounds__(256) void pyr_max_kernel(const D* __restrict__ in, int n_in,
+                                                      D* __restrict__ out, int n_out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_out) return;
+    const int lo = b << PYR_SHIFT, hi = min(lo + PYR, n_in);
+    D m = in[lo];
+    for (int i = lo + 1; i < hi; ++i) { const D v = in[i]; m = (m < v) ? v : m; }
+    out[b] = m;
+}
+
+__global__ __launch_bounds__(256) void pyr_box_kernel(const float* __restrict__ in, int n_in,
+                                                      float* __restrict__ out, int n_out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / 6, c = t % 6;
+    if (b >= n_out) return;
+    const int lo = b << PYR_SHIFT, hi = min(lo + PYR, n_in);
+    float m = in[6 * size_t(lo) + c];
+    for (int i = lo + 1; i < hi; ++i) {
+        const float v = in[6 * size_t(i) + c];
+        m = c < 3 ? fminf(m, v) : fmaxf(m, v);
+    }
+    out[6 * size_t(b) + c] = m;
+}
+
+// Largest i < j with !(d(i) < x), or -1.
+template <typename D>
+__device__ __forceinline__ int nearest_ge_left(const MaxPyramid<D>& p, int j, const D x)
+{
+    int pos = j - 1, lvl = 0;
+    while (pos >= 0) {
+        const int block0 = pos & ~(PYR - 1);
+        int e = pos;
+        for (; e >= block0; --e)
+            if (!(p.level[lvl][e] < x)) break;
+        if (e >= block0) { // found at this level: walk down to the element
+            while (lvl > 0) {
+                --lvl;
+                const int c0 = e << PYR_SHIFT;
+                int c = min(c0 + PYR - 1, p.size[lvl] - 1);
+                while (c > c0 && p.level[lvl][c] < x) --c; // bounded even for NaN input
+                e = c;
+            }
+            return e;
+        }
+        if (lvl + 1 >= p.levels) return -1;
+        pos = (block0 >> PYR_SHIFT) - 1;
+        ++lvl;
+    }
+    return -1;
+}
+
+// Smallest i > j with x < d(i), or n (= n_nodes, the right sentinel's index).
+template <typename D>
+__device__ __forceinline__ int nearest_gt_right(const MaxPyramid<D>& p, int j, const D x, int n)
+{
+    int pos = j + 1, lvl = 0;
+    while (pos < p.size[lvl]) {
+        const int block1 = min((pos | (PYR - 1)) + 1, p.size[lvl]); // end of pos's block
+        int e = pos;
+        for (; e < block1; ++e)
+            if (x < p.level[lvl][e]) break;
+        if (e < block1) {
+            while (lvl > 0) {
+                --lvl;
+                int c = e << PYR_SHIFT;
+                const int c1 = min(c + PYR, p.size[lvl]) - 1;
+                while (c < c1 && !(x < p.level[lvl][c])) ++c;
+                e = c;
+            }
+            return e;
+        }
+        if (lvl + 1 >= p.levels) return n;
+        pos = ((pos | (PYR - 1)) + 1) >> PYR_SHIFT;
+        ++lvl;
+    }
+    return n;
+}
+
+// Union of the leaf boxes lo .. hi (inclusive).
+__device__ __forceinline__ void box_union(const BoxPyramid& p, int lo, int hi, float* bot, float* top)
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { bot[c] = INFINITY; top[c] = -INFINITY; }
+    int a = lo, b = hi + 1, lvl = 0;
+    auto take = [&](int e) {
+        const float* q = p.level[lvl] + 6 * size_t(e);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { bot[c] = fminf(bot[c], q[c]); top[c] = fmaxf(top[c], q[3 + c]); }
+    };
+    while (a < b) {
+        while (a < b && (a & (PYR - 1))) take(a++);
+        while (a < b && (b & (PYR - 1))) take(--b);
+        if (a >= b) break;
+        if (lvl + 1 >= p.levels) { // top level: plain scan
+            while (a < b) take(a++);
+            break;
+        }
+        a >>= PYR_SHIFT; b >>= PYR_SHIFT; ++lvl;
+    }
+}
+
+// lds: leaf deltas with the reference's +1 shift (lds[k + 1] = d(k); lds[0], lds[n_leaves]
+// are the sentinels).  One thread per node and one per leaf.
+template <typename D>
+__global__ __launch_bounds__(256) void nodes_direct_kernel(const MaxPyramid<D> mp, const BoxPyramid bp,
+                                                           const D* __restrict__ lds, int n_leaves,
+                                                           int* __restrict__ nodes, int* __restrict__ root)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_nodes = n_leaves - 1;
+    if (t < n_nodes) {
+        const int j = t;
+        const D x = lds[j + 1];
+        const int first = nearest_ge_left(mp, j, x) + 1;
+        const int last = nearest_gt_right(mp, j, x, n_nodes);
+        int* np = nodes + 16 * size_t(j);
         float* nf = reinterpret_cast<float*>(np);
-        if (right_child) {
-            np[1] = cur;
-            np[3] = gr;
-            *reinterpret_cast<float4*>(nf + 8) = make_float4(bot[0], top[0], bot[1], top[1]);
-            *reinterpret_cast<float2*>(nf + 14) = make_float2(bot[2], top[2]);
+        np[2] = first;
+        np[3] = last;
+        float bot[3], top[3];
+        box_union(bp, first, j, bot, top);          // left child covers leaves first .. j
+        *reinterpret_cast<float4*>(nf + 4) = make_float4(bot[0], top[0], bot[1], top[1]);
+        *reinterpret_cast<float2*>(nf + 12) = make_float2(bot[2], top[2]);
+        box_union(bp, j + 1, last, bot, top);       // right child covers leaves j+1 .. last
+        *reinterpret_cast<float4*>(nf + 8) = make_float4(bot[0], top[0], bot[1], top[1]);
+        *reinterpret_cast<float2*>(nf + 14) = make_float2(bot[2], top[2]);
+        // d(first-1) < d(last): right child of node first-1, else left child of node `last`
+        // (albvh.cuh:465-505); the sentinels at either end are never a parent.
+        const bool right_child = first > 0 && (last == n_leaves - 1 || lds[first] < lds[last + 1]);
+        if (first == 0 && last == n_leaves - 1) {
+            *root = j;                               // albvh.cuh:572-573
+        } else if (right_child) {
+            nodes[16 * size_t(first - 1) + 1] = j;
         } else {
-            np[0] = cur;
-            np[2] = gl;
-            *reinterpret_cast<float4*>(nf + 4) = make_float4(bot[0], top[0], bot[1], top[1]);
-            *reinterpret_cast<float2*>(nf + 12) = make_float2(bot[2], top[2]);
+            nodes[16 * size_t(last)] = j;
         }
-        // Publish this child's half of node p, then count the arrival.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t before =
-            __hip_atomic_fetch_add(&arrivals[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (before == 0) break; // the sibling's thread will carry node p upward
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // Second arrival: read the sibling's half and continue as node p.
-        if (right_child) {
-            gl = np[2];
-            const float4 q = *reinterpret_cast<const float4*>(nf + 4);
-            const float2 z = *reinterpret_cast<const float2*>(nf + 12);
-            bot[0] = fminf(bot[0], q.x); top[0] = fmaxf(top[0], q.y);
-            bot[1] = fminf(bot[1], q.z); top[1] = fmaxf(top[1], q.w);
-            bot[2] = fminf(bot[2], z.x); top[2] = fmaxf(top[2], z.y);
-        } else {
-            gr = np[3];
-            const float4 q = *reinterpret_cast<const float4*>(nf + 8);
-            const float2 z = *reinterpret_cast<const float2*>(nf + 14);
-            bot[0] = fminf(bot[0], q.x); top[0] = fmaxf(top[0], q.y);
-            bot[1] = fminf(bot[1], q.z); top[1] = fmaxf(top[1], q.w);
-            bot[2] = fminf(bot[2], z.x); top[2] = fmaxf(top[2], z.y);
-        }
-        cur = p;
+    } else if (t < n_nodes + n_leaves) {
+        const int k = t - n_nodes;                   // leaf k: cluster [k, k]
+        const bool right_child = k > 0 && (k == n_leaves - 1 || lds[k] < lds[k + 1]);
+        if (right_child) nodes[16 * size_t(k - 1) + 1] = n_nodes + k;
+        else nodes[16 * size_t(k)] = n_nodes + k;
     }
 }
 
@@ -262,13 +378,37 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
         return set_error(GRACE_INVALID_ARGUMENT, __FILE__, __LINE__,
                          "build_ALBVH: fewer than two leaves (NaN deltas?)");
 
-    GRACE_TRY_HIP(hipMemsetAsync(arrivals, 0, size_t(n_leaves) * 4, stream));
     leaf_boxes_kernel<PRIM><<<ceil_div(size_t(n_leaves) * 8, 256), 256, 0, stream>>>(
         reinterpret_cast<const float4*>(d_spheres), reinterpret_cast<const int4*>(d_leaves),
         int(n_leaves), boxes);
     GRACE_CHECK_LAUNCH();
-    nodes_climb_kernel<D><<<ceil_div(n_leaves, 256), 256, 0, stream>>>(
-        boxes, int(n_leaves), leaf_ds, d_nodes, arrivals, d_root);
+    // Pyramids: maxima of the node deltas d(j) = leaf_ds[j + 1], and unions of the leaf boxes.
+    const int n_nodes = int(n_leaves) - 1;
+    MaxPyramid<D> mp;
+    BoxPyramid bp;
+    mp.levels = bp.levels = 1;
+    mp.level[0] = leaf_ds + 1; mp.size[0] = n_nodes;
+    bp.level[0] = boxes; bp.size[0] = int(n_leaves);
+    D* pyr_d = reinterpret_cast<D*>(flags);         // flags / counts / pos are dead by now
+    float* pyr_b = reinterpret_cast<float*>(arrivals);
+    while (mp.size[mp.levels - 1] > PYR && mp.levels < PYR_MAX_LEVELS) {
+        const int n_in = mp.size[mp.levels - 1], n_out = (n_in + PYR - 1) / PYR;
+        pyr_max_kernel<D><<<ceil_div(n_out, 256), 256, 0, stream>>>(mp.level[mp.levels - 1], n_in,
+                                                                    pyr_d, n_out);
+        GRACE_CHECK_LAUNCH();
+        mp.level[mp.levels] = pyr_d; mp.size[mp.levels] = n_out; ++mp.levels;
+        pyr_d += (n_out + 63) & ~63;
+    }
+    while (bp.size[bp.levels - 1] > PYR && bp.levels < PYR_MAX_LEVELS) {
+        const int n_in = bp.size[bp.levels - 1], n_out = (n_in + PYR - 1) / PYR;
+        pyr_box_kernel<<<ceil_div(size_t(n_out) * 6, 256), 256, 0, stream>>>(bp.level[bp.levels - 1],
+                                                                             n_in, pyr_b, n_out);
+        GRACE_CHECK_LAUNCH();
+        bp.level[bp.levels] = pyr_b; bp.size[bp.levels] = n_out; ++bp.levels;
+        pyr_b += (size_t(n_out) * 6 + 63) & ~size_t(63);
+    }
+    nodes_direct_kernel<D><<<ceil_div(size_t(n_nodes) + n_leaves, 256), 256, 0, stream>>>(
+        mp, bp, leaf_ds, int(n_leaves), d_nodes, d_root);
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
 }
