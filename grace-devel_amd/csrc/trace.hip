@@ -591,14 +591,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             const float4 R = np[2];
             const float4 Z = np[3];
             int2 span = make_int2(0, 0x7fffffff);
+#ifdef GRACE_PACKET_STATS
+            if (a.treelet > 0) span = a.node_prims[idx];
+#else
             if (MODE != MODE_STATS && a.treelet > 0) span = a.node_prims[idx];
+#endif
             if (span.y <= a.treelet) {
                 sweep = true; sweep_first = span.x; sweep_count = span.y;
             } else {
             const int lr = aabbs_hit(ix, iy, iz, ox, oy, oz, len, L, R, Z);
             const bool hit_r = lr & 1, hit_l = lr >= 2;
 #ifdef GRACE_PACKET_STATS
-            if (MODE == MODE_STATS) ++st_nodes;
 #else
             if (MODE == MODE_STATS && alive) ++st_nodes;
 #endif
@@ -717,6 +720,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                             b2 = bx * bx + by * by + bz * bz;
                         }
                         const bool hit = !(b2 >= s.w) && !(dot_p < 0.0f) && !(dot_p >= len);
+#ifdef GRACE_PACKET_STATS
+                        if (MODE == MODE_STATS && __builtin_amdgcn_ballot_w64(hit) != 0ull) ++st_nodes;
+#endif
                         if (MODE == MODE_COUNT || MODE == MODE_STATS) {
                             count += hit ? 1 : 0;
                         } else if (hit) {
@@ -805,7 +811,11 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         // is latency-bound and shorter sweeps win (measured: 10^7 spheres / 1024^2 rays vs
         // 10^6 spheres / 10^5 rays).
         const int auto_treelet = ceil_div(n_rays, 64) >= 4096 ? 512 : 256;
+#ifdef GRACE_PACKET_STATS
+        a.treelet = g_treelet < 0 ? auto_treelet : g_treelet;
+#else
         a.treelet = (MODE == MODE_STATS) ? 0 : (g_treelet < 0 ? auto_treelet : g_treelet);
+#endif
         if (reorder) {
             uint32_t* ext = Workspace::take<uint32_t>(12);
             uint32_t* keys = Workspace::take<uint32_t>(n_rays);
