@@ -7,8 +7,16 @@ semantics) on the project_gadget workload -- 10^7 particles, 1024^2 orthographic
 
 One process per GPU (torch.distributed / RCCL when N > 1): every rank builds the same BVH
 from the same seeded particles (the tree is replicated), traces its own contiguous shard of
-the ray grid, and the per-ray integrals are all-gathered over RCCL.  A "step" = one trace of
-the whole ray batch (+ the gather when N > 1) with particles, tree and rays resident in HBM.
+the job's ray batch, and the per-ray integrals are all-gathered over RCCL (the only
+collective; 4 B/ray).  A "step" = one trace of the whole ray batch (+ the gather when N > 1)
+with particles, tree and rays resident in HBM.
+
+  --scaling weak (default): the job is N frames of the 1024^2 image -- frame 0 is the
+      pixel-centre grid of configs[3], frame r > 0 the same grid shifted by a fixed sub-pixel
+      offset (an N-sample supersampled projection) -- so every rank traces 1024^2 rays of the
+      same statistical character whatever N is; a rank's contiguous shard is its frame.
+  --scaling strong: the job is the single 1024^2 frame, cut into N contiguous shards.
+
 Rank 0 prints ONE JSON line.  The oracle is used only by the cpu_baseline leg (rank 0,
 N = 1) as the thing timed on the host cores, never in the GPU path.
 """
@@ -77,6 +85,7 @@ def main():
     ap.add_argument("--particles", type=int, default=10_000_000)
     ap.add_argument("--side", type=int, default=1024)
     ap.add_argument("--max-per-leaf", type=int, default=32)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,13 +132,25 @@ def main():
     del unsorted
     del keys, deltas
 
-    # ---- rays: the full grid, then this rank's contiguous shard (multiple of 64) --------
+    # ---- rays: this rank's contiguous shard (a multiple of 64) of the job's ray batch -----
     from grace_hip import sharding
     rays, area = gh.orthogonal_rays_z(args.side, lo, hi, device=device)
-    n_rays = len(rays)
+    frame_rays = len(rays)
+    frames = world if args.scaling == "weak" else 1
+    n_rays = frames * frame_rays
     per = sharding.shard_size(n_rays, world)
     r0, r1 = sharding.shard_bounds(n_rays, world, rank)
-    my_rays = rays[r0:r1].contiguous()
+    if frames > 1:
+        # shard == frame `rank` (side^2 is a multiple of 64): shift the grid by this frame's
+        # sub-pixel offset (R2 low-discrepancy sequence, |offset| <= 1/4 pixel: stays in the box)
+        assert per == frame_rays and r0 == rank * frame_rays
+        fx = ((rank * 0.7548776662466927) % 1.0 - 0.5) * 0.5 if rank else 0.0
+        fy = ((rank * 0.5698402909980532) % 1.0 - 0.5) * 0.5 if rank else 0.0
+        my_rays = rays.clone()
+        my_rays[:, 3] += fx * float(hi[0] - lo[0]) / args.side
+        my_rays[:, 4] += fy * float(hi[1] - lo[1]) / args.side
+    else:
+        my_rays = rays[r0:r1].contiguous()
     my_out = torch.zeros(per, dtype=torch.float32, device=device)
     image = my_out
 
@@ -191,20 +212,22 @@ def main():
                 traffic = json.load(open(tfile)).get("trace_cumulative_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        img = image[:n_rays]
+        img = image[:frame_rays]   # frame 0
         out = {
             "metric": "Mrays/s SPH column-density trace, 10^7 particles",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "project_gadget: %d uniform-random SPH particles "
                                    "(h = 48-neighbour rule), %dx%d orthographic -z rays, "
                                    "max_per_leaf %d" % (n, args.side, args.side,
                                                         args.max_per_leaf),
-                       "particles": n, "rays": n_rays, "max_per_leaf": args.max_per_leaf,
-                       "sharding": "rays contiguous over %d rank(s), BVH replicated, "
-                                   "all_gather of 4 B/ray" % world},
+                       "particles": n, "rays": n_rays, "frames": frames,
+                       "max_per_leaf": args.max_per_leaf,
+                       "sharding": "%d frame(s) of %d rays, contiguous ray shards over %d "
+                                   "rank(s), BVH replicated, all_gather of 4 B/ray"
+                                   % (frames, frame_rays, world)},
             "roofline": {"bound": "hbm", "kernel": "trace_kernel<cumulative>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

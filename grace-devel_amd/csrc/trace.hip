@@ -58,6 +58,24 @@
 //     That keeps scalar-memory round trips and their address arithmetic out of the inner
 //     loop, lets the sphere test run on VGPR operands (2.6 instead of 4.3 cycles per
 //     instruction on gfx950) and decouples the table lookup's LDS wait from prefetches;
+//   * class-ordered sums and packet splitting: primitives are dealt to 8 CLASSES in granules
+//     of 1024 consecutive indices (class = (index >> 10) & 7).  A ray's column density is
+//     defined as the balanced pairwise (binary-tree) fp32 sum of its 8 class sums, each class
+//     summed in ascending primitive order.  The value is a function of the ray and the scene
+//     only -- not of how rays are batched, ordered or sharded -- and differs from the
+//     reference's single running sum only in the last bits (both within 1e-6 of the exact
+//     sum; tolerance 1e-5).  What it buys: a packet can be walked by K = 1, 2, 4 or 8
+//     waves, wave k owning the 8/K classes [k 8/K, (k+1) 8/K) -- a subtree of the summation
+//     tree, and, because classes interleave along the Morton order, an even share of the
+//     work for any beam -- with NO change of the result: each wave reduces its classes, a
+//     tiny kernel finishes the tree.  K is the smallest power of two that puts >= 32768 waves
+//     in flight (measured: K = 2 already helps the full 1024^2 image by evening out the
+//     packets' very different walk lengths; one eighth of the image on one of eight GPUs, or
+//     10^5 source rays, want K = 8: one wave per packet leaves the SIMDs idle there).  A wave
+//     keeps its class accumulators in LDS (8 classes: 2 KiB per wave, so that LDS does not cap
+//     occupancy below the VGPR limit of 8 waves/SIMD) and switches at granule boundaries, once
+//     per culling round at most (the walk meets primitives in ascending order).  Hit counts
+//     split the same way (integers);
 //   * packets are dealt to workgroups so that the workgroups sharing an XCD (blockIdx % 8)
 //     walk a contiguous range of packets: neighbouring packets touch the same subtree and
 //     each XCD's 4 MiB L2 keeps it.
@@ -75,6 +93,8 @@ namespace {
 
 constexpr int TRACE_BLOCK = 256;
 constexpr int N_TABLE = 51;
+constexpr int SUM_CLASSES = 8;   // summation classes (leaves of the pairwise sum tree)
+constexpr int GRANULE_SHIFT = 10; // 1024 consecutive primitives share a class
 
 // include/grace/cuda/trace_sph.cuh:32-48
 __constant__ double c_kernel_table[N_TABLE] = {
@@ -107,6 +127,9 @@ struct TraceArgs {
     const float4* A;        // pre-pass: {x, y, z, h*h}, padded by 4 entries
     const float2* B;        // pre-pass: {1/h, (1/h)^2}, padded by 4 entries
     const double* T64;      // MODE_TRI pre-pass: {v, e1, e2} widened to fp64, 9 per triangle
+    int split;              // waves per packet (1, 2, 4, 8); each owns SUM_CLASSES / split classes
+    int n_prims;
+    float* partial;         // split > 1, cumulative: [n_rays][split] subtree sums
     const float4* nodes;    // 4 x float4 per node
     int n_nodes;
     const int4* leaves;
@@ -460,7 +483,7 @@ __device__ __forceinline__ bool beam_may_hit(const float4 s, const Beam& bm)
     return !(b2_lo >= s.w);
 }
 
-template <int MODE>
+template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
 {
     __shared__ double2 s_lut[N_TABLE];
@@ -483,10 +506,24 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     // correctness): give each XCD a contiguous run of packets.
     const int nb = gridDim.x, q = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int vblock = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
-    const int packet = __builtin_amdgcn_readfirstlane(vblock * (TRACE_BLOCK / 64)
-                                                      + (threadIdx.x >> 6));
+    const int wave_id = __builtin_amdgcn_readfirstlane(vblock * (TRACE_BLOCK / 64)
+                                                       + (threadIdx.x >> 6));
+    constexpr bool SPLITTABLE = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE);
+    static_assert(!SPLIT || SPLITTABLE, "only hit counts and column densities split");
+    const int split = SPLIT ? a.split : 1;
+    const int packet = wave_id / split, part = wave_id - packet * split;
     const int first_ray = packet * 64;
     if (first_ray >= a.n_rays) return;
+    // Summation classes owned by this wave: [own_lo, own_hi).
+    const int classes_per_part = SUM_CLASSES / split;
+    const int own_lo = part * classes_per_part, own_hi = own_lo + classes_per_part;
+    auto owns_granule = [&](const int g) { const int c = g & (SUM_CLASSES - 1); return c >= own_lo && c < own_hi; };
+    // True if no primitive of [first, first + count) belongs to this wave (ranges of up to
+    // two granules are decided exactly; longer ones are descended / swept).
+    auto foreign_range = [&](const int first, const int count) {
+        const int g0 = first >> GRANULE_SHIFT, g1 = (first + count - 1) >> GRANULE_SHIFT;
+        return g1 - g0 <= 1 && !owns_granule(g0) && !owns_granule(g1);
+    };
     const int slot_index = first_ray + lane;
     const bool valid = slot_index < a.n_rays;
     // Tail lanes re-trace the last ray so that they do not widen the packet.
@@ -523,7 +560,25 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     const float o2 = axis == 2 ? oy : oz;
 
     int count = 0;
-    float sum = 0.f;
+    float sum = 0.f;        // accumulator of the current granule's class (MODE_CUMULATIVE)
+    // Class accumulators of this wave's lanes (one wave = one row of the workgroup's array).
+    constexpr bool CLASSES = (MODE == MODE_CUMULATIVE);
+    __shared__ float s_class[CLASSES ? TRACE_BLOCK / 64 : 1][CLASSES ? SUM_CLASSES : 1][CLASSES ? 64 : 1];
+    const int wv_acc = threadIdx.x >> 6;
+    if (CLASSES) {
+#pragma unroll
+        for (int c = 0; c < SUM_CLASSES; ++c) s_class[wv_acc][c][lane] = 0.f;
+    }
+    int cur_granule = -1;            // wave-uniform
+    int cur_granule_end = 0;         // first primitive past the current granule
+    bool cur_owned = true;
+    auto enter_granule = [&](const int prim) {
+        if (cur_granule >= 0) s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane] = sum;
+        cur_granule = prim >> GRANULE_SHIFT;
+        cur_granule_end = (cur_granule + 1) << GRANULE_SHIFT;
+        cur_owned = !SPLIT || owns_granule(cur_granule);
+        sum = s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane];
+    };
     int write_at = 0;
     // MODE_TRI: RayEntry_tri (tris_trace.cuh:63-73): closest index -1, t_min = length (1 + eps)
     int tri_data = -1;
@@ -594,8 +649,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
 #ifdef GRACE_PACKET_STATS
             if (a.treelet > 0) span = a.node_prims[idx];
 #else
-            if (MODE != MODE_STATS && a.treelet > 0) span = a.node_prims[idx];
+            if (MODE != MODE_STATS && (a.treelet > 0 || SPLIT)) span = a.node_prims[idx];
 #endif
+            // A wave of a split packet skips subtrees outside its primitive range.
+            if (SPLIT && foreign_range(span.x, span.y)) continue;
             if (span.y <= a.treelet) {
                 sweep = true; sweep_first = span.x; sweep_count = span.y;
             } else {
@@ -614,6 +671,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             }
         } else {
             const int4 lf = a.leaves[idx - a.n_nodes];
+            if (SPLIT && foreign_range(lf.x, lf.y)) continue;
             sweep = true; sweep_first = lf.x; sweep_count = lf.y;
 #ifndef GRACE_PACKET_STATS
             if (MODE == MODE_STATS && alive) { ++st_leaves; st_tested += uint32_t(lf.y); }
@@ -653,17 +711,36 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     if (LDS_TILE && NEED_B) mineb_next = pb[nj < leaf.y ? nj : base + 64];
                 }
                 const bool keep = lane < m && beam_may_hit(mine, beam);
-                unsigned long long todo = __builtin_amdgcn_ballot_w64(keep);
+                unsigned long long rest = __builtin_amdgcn_ballot_w64(keep);
 #ifdef GRACE_PACKET_STATS
-                if (MODE == MODE_STATS) { st_leaves += 1; st_tested += __builtin_popcountll(todo); }
+                if (MODE == MODE_STATS) { st_leaves += 1; st_tested += __builtin_popcountll(rest); }
 #endif
-                if (todo == 0ull) continue;
+                if (rest == 0ull) continue;
                 const int wv = threadIdx.x >> 6;
                 if (LDS_TILE) {
                     // Stage the round's candidates; survivors are then broadcast-read from LDS
                     // into VGPRs (in-order LDS returns, no scalar-load round trips, VGPR operands).
                     s_tileA[wv][lane] = mine;
                     if (NEED_B) s_tileB[wv][lane] = mineb;
+                }
+                // The round's survivors are taken granule by granule (a round of 64 consecutive
+                // primitives touches at most two), so that the class accumulator switch and the
+                // ownership test of a split packet stay out of the per-survivor loop.
+#pragma nounroll
+                while (rest != 0ull) {
+                unsigned long long todo = rest;
+                rest = 0ull;
+                if (CLASSES || SPLIT) {
+                    const int p0 = leaf.x + base;
+                    const int pf = p0 + __builtin_ctzll(todo);
+                    const int cut = (((pf >> GRANULE_SHIFT) + 1) << GRANULE_SHIFT) - p0;
+                    if (cut < 64) {
+                        const unsigned long long below = (1ull << cut) - 1ull;
+                        rest = todo & ~below;
+                        todo &= below;
+                    }
+                    if (CLASSES && pf >= cur_granule_end) enter_granule(pf); // ascending index
+                    if (SPLIT && !(CLASSES ? cur_owned : owns_granule(pf >> GRANULE_SHIFT))) continue;
                 }
                 int j = base + __builtin_ctzll(todo);
                 todo &= todo - 1ull;
@@ -742,6 +819,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     curb = nxtb;
                     j = jn;
                 }
+                } // granule chunks of the round
             }
             };
             switch (axis) {
@@ -757,9 +835,36 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
 
     if ((overflow || junk < 0) && lane == 0) *a.status = GRACE_STACK_OVERFLOW;
     if (!valid) return;
-    if (MODE == MODE_COUNT) a.out_counts[ray_index] = count;
+    if (MODE == MODE_COUNT) {
+        if (!SPLIT) a.out_counts[ray_index] = count;
+        else if (count) atomicAdd(&a.out_counts[ray_index], count); // output zeroed by the host
+    }
     if (MODE == MODE_TRI) a.out_counts[ray_index] = tri_data;
-    if (MODE == MODE_CUMULATIVE) a.out_sums[ray_index] = sum;
+    if (MODE == MODE_CUMULATIVE) {
+        if (cur_granule >= 0) s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane] = sum;
+        // Pairwise sum of this wave's classes (a subtree of the summation tree).
+        float t[SUM_CLASSES];
+#pragma unroll
+        for (int c = 0; c < SUM_CLASSES; ++c) t[c] = s_class[wv_acc][c][lane];
+        float result = 0.f;
+        if (!SPLIT) {
+#pragma unroll
+            for (int w = 1; w < SUM_CLASSES; w *= 2)
+#pragma unroll
+                for (int c = 0; c < SUM_CLASSES; c += 2 * w) t[c] = t[c] + t[c + w];
+            result = t[0];
+            a.out_sums[ray_index] = result;
+        } else {
+            // classes own_lo .. own_hi-1: reduce with the same pairing, then publish
+            for (int w = 1; w < classes_per_part; w *= 2)
+                for (int c = own_lo; c < own_hi; c += 2 * w) {
+                    // t[] is indexed with wave-uniform runtime indices only here (rare path)
+                    const float x = s_class[wv_acc][c][lane], y = s_class[wv_acc][c + w][lane];
+                    s_class[wv_acc][c][lane] = x + y;
+                }
+            a.partial[size_t(ray_index) * split + part] = s_class[wv_acc][own_lo][lane];
+        }
+    }
     if (MODE == MODE_STATS) {
         reinterpret_cast<uint4*>(a.stats)[ray_index] =
             make_uint4(st_nodes, st_leaves, st_tested, uint32_t(count));
@@ -780,6 +885,22 @@ grace_status ensure_status(hipStream_t stream)
     return GRACE_OK;
 }
 
+// Upper levels of the pairwise summation tree for split packets: K subtree sums per ray.
+__global__ __launch_bounds__(256) void combine_classes_kernel(const float* __restrict__ partial,
+                                                              int n_rays, int split,
+                                                              float* __restrict__ out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    float t[SUM_CLASSES];
+    for (int k = 0; k < split; ++k) t[k] = partial[size_t(r) * split + k];
+    for (int w = 1; w < split; w *= 2)
+        for (int k = 0; k < split; k += 2 * w) t[k] = t[k] + t[k + w];
+    out[r] = t[0];
+}
+
+int g_split = -1; // waves per packet; -1: automatic
+
 template <int MODE>
 grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n_nodes,
                           hipStream_t stream)
@@ -796,12 +917,14 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                                    + Workspace::aligned((n_spheres + 4) * sizeof(float2))
                                    + Workspace::aligned(n_nodes * sizeof(int2))
                                    + (MODE == MODE_TRI ? Workspace::aligned(72 * (n_spheres + 4)) : 0)
+                                   + (MODE == MODE_CUMULATIVE ? Workspace::aligned(n_rays * SUM_CLASSES * 4) : 0)
                                    + (reorder ? 2 * Workspace::aligned(n_rays * 4)
                                                 + sort_ws_bytes(n_rays, 4, 0) : 0) + 1024));
         float4* A = Workspace::take<float4>(n_spheres + 4);
         float2* B = need_b ? Workspace::take<float2>(n_spheres + 4) : nullptr;
         double* T64 = (MODE == MODE_TRI) ? Workspace::take<double>(9 * (n_spheres + 4)) : nullptr;
         a.T64 = T64;
+        a.partial = (MODE == MODE_CUMULATIVE) ? Workspace::take<float>(n_rays * SUM_CLASSES) : nullptr;
         int2* node_prims = Workspace::take<int2>(n_nodes);
         node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
             reinterpret_cast<const int4*>(a.nodes), a.leaves, int(n_nodes), node_prims);
@@ -845,6 +968,16 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     a.n_nodes = int(n_nodes);
     a.status = g_status;
     const int n_packets = ceil_div(n_rays, 64);
+    // Waves per packet: enough waves to fill the chip (8192 resident) for small ray batches.
+    int split = 1;
+    if (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) {
+        if (g_split > 0) split = g_split;
+        else while (split < SUM_CLASSES && size_t(n_packets) * split < 32768) split *= 2;
+    }
+    a.split = split;
+    a.n_prims = int(n_spheres);
+    if (split > 1 && MODE == MODE_COUNT)
+        GRACE_TRY_HIP(hipMemsetAsync(a.out_counts, 0, n_rays * sizeof(int), stream));
     if (g_timing) {
         if (!g_ev0) {
             GRACE_TRY_HIP(hipEventCreate(&g_ev0));
@@ -852,8 +985,19 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         }
         GRACE_TRY_HIP(hipEventRecord(g_ev0, stream));
     }
-    trace_kernel<MODE><<<ceil_div(n_packets, TRACE_BLOCK / 64), TRACE_BLOCK, 0, stream>>>(a);
+    const int grid = ceil_div(size_t(n_packets) * split, TRACE_BLOCK / 64);
+    if constexpr (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) {
+        if (split > 1) trace_kernel<MODE, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        else trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+    } else {
+        trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+    }
     GRACE_CHECK_LAUNCH();
+    if (MODE == MODE_CUMULATIVE && split > 1) {
+        combine_classes_kernel<<<ceil_div(n_rays, 256), 256, 0, stream>>>(a.partial, int(n_rays),
+                                                                          split, a.out_sums);
+        GRACE_CHECK_LAUNCH();
+    }
     if (g_timing) {
         GRACE_TRY_HIP(hipEventRecord(g_ev1, stream));
         g_ev_valid = true;
@@ -974,6 +1118,15 @@ grace_status grace_trace_last_kernel_ms(float* h_ms)
     GRACE_REQUIRE(g_timing && g_ev_valid, "no timed traversal launch recorded");
     GRACE_TRY_HIP(hipEventSynchronize(g_ev1));
     GRACE_TRY_HIP(hipEventElapsedTime(h_ms, g_ev0, g_ev1));
+    return GRACE_OK;
+}
+
+grace_status grace_trace_set_packet_split(int waves_per_packet)
+{
+    GRACE_REQUIRE(waves_per_packet == -1 || waves_per_packet == 1 || waves_per_packet == 2
+                      || waves_per_packet == 4 || waves_per_packet == 8,
+                  "packet split must be 1, 2, 4, 8 or -1 (automatic)");
+    g_split = waves_per_packet;
     return GRACE_OK;
 }
 

@@ -261,6 +261,10 @@ def last_kernel_ms():
     return ms.value
 
 
+def set_packet_split(k):
+    _check(_lib.grace_trace_set_packet_split(C.c_int(int(k))))
+
+
 def set_treelet_size(n):
     _check(_lib.grace_trace_set_treelet_size(C.c_int(int(n))))
 

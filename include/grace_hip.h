@@ -189,6 +189,12 @@ grace_status grace_trace_set_ray_reorder(int enabled);
 grace_status grace_trace_enable_timing(int enabled);
 grace_status grace_trace_last_kernel_ms(float* h_ms);
 
+/* Waves per 64-ray packet for the hit-count and cumulative traces: 1, 2, 4 or 8 (each wave
+ * owns 8/K of the 8 interleaved primitive classes over which the column density is summed), or
+ * -1 (default) = as many as it takes to put >= 32768 waves on the chip.  The results do not
+ * depend on it (see csrc/trace.hip, "class-ordered sums and packet splitting"). */
+grace_status grace_trace_set_packet_split(int waves_per_packet);
+
 /* Subtrees with at most this many primitives are swept in one culling pass instead of being
  * descended (results per ray unchanged).  0 disables; -1 (default) picks 512 when the call
  * has >= 4096 packets of 64 rays, else 256. */

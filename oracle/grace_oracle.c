@@ -548,23 +548,54 @@ void go_brute_hitcounts(const go_ray* rays, size_t n_rays, const go_f4* s, size_
     }
 }
 
-/* Cumulative integral, hits visited in ascending primitive index: the order in
- * which trace_kernel meets them (bintree_trace.cuh:128-192: left child pushed last,
- * so popped first; leaves scanned first..first+count).  fp32 running sum as
- * RayData_sphere<float,float>.data; out64 (optional) is the same sum in fp64. */
-void go_brute_cumulative(const go_ray* rays, size_t n_rays, const go_f4* s, size_t n,
-                         float* out, double* out64)
+/* Column density of one ray.  Hits are visited in ascending primitive index: the order in
+ * which trace_kernel meets them (bintree_trace.cuh:128-192: left child pushed last, so popped
+ * first; leaves scanned first..first+count).  The reference keeps ONE fp32 running sum
+ * (RayData_sphere<float,float>.data).  This implementation's stated result is the
+ * CLASS-ORDERED sum: primitive p belongs to class (p >> 10) & 7 (granules of 1024 consecutive
+ * indices dealt round-robin to 8 classes); each class is summed in ascending primitive
+ * order and the 8 class sums are added pairwise, ((c0+c1)+(c2+c3))+((c4+c5)+(c6+c7)) -- a fixed
+ * association that lets up to 8 waves share a packet with an even share of the work each
+ * (DESIGN.md section 4).  blocks = 1 gives the reference's single running sum; both lie
+ * within ~1e-6 of the fp64 sum (tolerance 1e-5). */
+#define GO_SUM_CLASSES 8
+#define GO_GRANULE_SHIFT 10
+typedef struct { float cls[GO_SUM_CLASSES]; int classes; } go_acc;
+static inline void acc_init(go_acc* a, size_t n, int blocks)
 {
+    (void)n;
+    for (int c = 0; c < GO_SUM_CLASSES; ++c) a->cls[c] = 0.f;
+    a->classes = blocks > 1 ? GO_SUM_CLASSES : 1;
+}
+static inline void acc_add(go_acc* a, long prim, float w)
+{
+    const int c = a->classes > 1 ? (int)((prim >> GO_GRANULE_SHIFT) & (GO_SUM_CLASSES - 1)) : 0;
+    a->cls[c] += w;
+}
+static inline float acc_result(go_acc* a)
+{
+    float t[GO_SUM_CLASSES];
+    for (int c = 0; c < GO_SUM_CLASSES; ++c) t[c] = a->cls[c];
+    for (int w = 1; w < GO_SUM_CLASSES; w *= 2)
+        for (int c = 0; c < GO_SUM_CLASSES; c += 2 * w) t[c] = t[c] + t[c + w];
+    return t[0];
+}
+
+void go_brute_cumulative(const go_ray* rays, size_t n_rays, const go_f4* s, size_t n,
+                         float* out, double* out64, int blocks)
+{
+    if (blocks < 1) blocks = 1;
     #pragma omp parallel for schedule(dynamic, 16)
     for (size_t ri = 0; ri < n_rays; ++ri) {
         go_ray ray = rays[ri];
-        float acc = 0.f; double acc64 = 0.0; float b2, d;
+        go_acc acc; acc_init(&acc, n, blocks);
+        double acc64 = 0.0; float b2, d;
         for (size_t si = 0; si < n; ++si)
             if (sphere_hit(&ray, &s[si], &b2, &d)) {
                 float w = hit_integral(b2, s[si].w);
-                acc += w; acc64 += (double)w;
+                acc_add(&acc, (long)si, w); acc64 += (double)w;
             }
-        out[ri] = acc;
+        out[ri] = acc_result(&acc);
         if (out64) out64[ri] = acc64;
     }
 }
@@ -601,9 +632,9 @@ void go_brute_hits(const go_ray* rays, size_t n_rays, const go_f4* s, size_t n,
  * algorithmic-bytes formula needs. */
 int go_trace(const go_ray* rays, size_t n_rays, const go_f4* s, size_t n_prims,
              const float* nodes, size_t n_nodes, const go_i4* leaves, int root,
-             int width, int mode, void* out, uint64_t* stats)
+             int width, int mode, void* out, uint64_t* stats, int blocks)
 {
-    (void)n_prims;
+    if (blocks < 1) blocks = 1;
     if (width < 1 || width > 64) return -2;
     int overflow = 0;
     size_t n_packets = (n_rays + width - 1) / width;
@@ -615,7 +646,8 @@ int go_trace(const go_ray* rays, size_t n_rays, const go_f4* s, size_t n_prims,
         unsigned char* act = NULL; /* per stack slot, per lane: lane alone reaches it */
         if (stats) act = (unsigned char*)malloc((size_t)GO_STACK * w);
         float* invd = (float*)malloc(sizeof(float) * 3 * w);
-        float* acc = (float*)calloc(w, sizeof(float));
+        go_acc* acc = (go_acc*)malloc(sizeof(go_acc) * w);
+        for (int l = 0; l < w; ++l) acc_init(&acc[l], n_prims, blocks);
         int* cnt = (int*)calloc(w, sizeof(int));
         for (int l = 0; l < w; ++l) {
             invd[3*l+0] = 1.f / rays[r0+l].dx;
@@ -662,7 +694,7 @@ int go_trace(const go_ray* rays, size_t n_rays, const go_f4* s, size_t n_prims,
                         float b2, d;
                         if (sphere_hit(r, &s[leaf.x + i], &b2, &d)) {
                             cnt[l]++;
-                            if (mode == 1) acc[l] += hit_integral(b2, s[leaf.x + i].w);
+                            if (mode == 1) acc_add(&acc[l], leaf.x + i, hit_integral(b2, s[leaf.x + i].w));
                         }
                     }
                 }
@@ -670,7 +702,7 @@ int go_trace(const go_ray* rays, size_t n_rays, const go_f4* s, size_t n_prims,
         }
         for (int l = 0; l < w; ++l) {
             if (mode == 0) ((int*)out)[r0+l] = cnt[l];
-            else ((float*)out)[r0+l] = acc[l];
+            else ((float*)out)[r0+l] = acc_result(&acc[l]);
             if (stats) stats[4*(r0+l)+3] = cnt[l];
         }
         free(invd); free(acc); free(cnt);

@@ -193,11 +193,15 @@ def brute_hitcounts(rays, prims):
     return out
 
 
-def brute_cumulative(rays, prims):
+SUM_BLOCKS = 8   # the class-ordered pairwise fp32 sum this implementation states (grace_oracle.c)
+
+
+def brute_cumulative(rays, prims, blocks=SUM_BLOCKS):
+    """(fp32 class-ordered pairwise sum, fp64 sum).  blocks=1: the reference's single running sum."""
     rays = _rays(rays); prims = _f4(prims)
     out = np.empty(len(rays), np.float32); out64 = np.empty(len(rays), np.float64)
     lib().go_brute_cumulative(_p(rays), C.c_size_t(len(rays)), _p(prims),
-                              C.c_size_t(len(prims)), _p(out), _p(out64))
+                              C.c_size_t(len(prims)), _p(out), _p(out64), C.c_int(blocks))
     return out, out64
 
 
@@ -214,7 +218,7 @@ def brute_hits(rays, prims):
     return offsets, idx, integ, dist
 
 
-def trace(rays, prims, nodes, leaves, root, width=32, mode=0, stats=False):
+def trace(rays, prims, nodes, leaves, root, width=32, mode=0, stats=False, blocks=SUM_BLOCKS):
     rays = _rays(rays); prims = _f4(prims)
     nodes = np.ascontiguousarray(nodes); leaves = np.ascontiguousarray(leaves, np.int32)
     out = np.empty(len(rays), np.int32 if mode == 0 else np.float32)
@@ -222,7 +226,7 @@ def trace(rays, prims, nodes, leaves, root, width=32, mode=0, stats=False):
     rc = lib().go_trace(_p(rays), C.c_size_t(len(rays)), _p(prims), C.c_size_t(len(prims)),
                         _p(nodes), C.c_size_t(len(nodes)), _p(leaves), C.c_int(root),
                         C.c_int(width), C.c_int(mode), _p(out),
-                        _p(st) if stats else None)
+                        _p(st) if stats else None, C.c_int(blocks))
     if rc != 0:
         raise RuntimeError("oracle traversal stack overflow / bad width")
     return (out, st) if stats else out

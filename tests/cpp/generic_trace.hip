@@ -4,6 +4,7 @@
 // hit"), checked against the built-in C-ABI kernels and a host loop.  Build with hipcc.
 #include "grace/hip/trace.hpp"
 
+#include <cmath>
 #include <cstdio>
 #include <vector>
 
@@ -55,8 +56,10 @@ int main()
         grace::RayEntry_null(), grace::RayExit_to_array<float>(s_generic.data()));
     grace::trace_cumulative_sph(d_rays, d_spheres, tree, s_builtin);
     const std::vector<float> sa = s_generic.to_host(), sb = s_builtin.to_host();
+    // The generic kernel keeps the reference's single running sum; the built-in kernel states the
+    // block-ordered sum: equal to a few ulp.
     size_t bad_sums = 0;
-    for (size_t i = 0; i < R; ++i) bad_sums += std::memcmp(&sa[i], &sb[i], 4) != 0;
+    for (size_t i = 0; i < R; ++i) bad_sums += !(std::fabs(sa[i] - sb[i]) <= 2e-6f * std::fabs(sb[i]));
 
     // user-defined functor vs a host loop
     grace::device_vector<int> d_big(R);

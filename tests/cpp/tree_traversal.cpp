@@ -13,7 +13,7 @@ extern "C" {
 void go_random_real4(uint32_t first, size_t n, const float* lo, const float* hi, void* out);
 void go_brute_hitcounts(const void* rays, size_t n_rays, const void* s, size_t n, int* counts);
 void go_brute_cumulative(const void* rays, size_t n_rays, const void* s, size_t n, float* out,
-                         double* out64);
+                         double* out64, int blocks);
 }
 
 int main(int argc, char* argv[])
@@ -87,7 +87,7 @@ int main(int argc, char* argv[])
     std::vector<grace::Ray> hr = prays.to_host();
     std::vector<float> ref32(hr.size());
     std::vector<double> ref64(hr.size());
-    go_brute_cumulative(hr.data(), hr.size(), hp.data(), Np, ref32.data(), ref64.data());
+    go_brute_cumulative(hr.data(), hr.size(), hp.data(), Np, ref32.data(), ref64.data(), 8);
     std::vector<float> img = image.to_host();
     size_t image_mismatch = 0;
     for (size_t i = 0; i < img.size(); ++i)

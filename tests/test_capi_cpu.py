@@ -145,3 +145,15 @@ def test_gadget_roundtrip_python_and_cpp(tmp_path):
         sums = [float(x) for x in out[1:5]]
         ref = [float(pos[:, k].astype(np.float64).sum()) for k in range(3)] + [float(h.astype(np.float64).sum())]
         assert np.allclose(sums, ref, rtol=1e-12)
+
+
+def test_weak_scaling_shard_is_one_frame():
+    """bench.py --scaling weak: the job is `world` frames of side^2 rays; each rank's contiguous
+    shard must be exactly its own frame (side^2 is a multiple of 64)."""
+    from grace_hip import sharding
+    frame = 1024 * 1024
+    for world in (1, 2, 4, 8):
+        n = world * frame
+        assert sharding.shard_size(n, world) == frame
+        for r in range(world):
+            assert sharding.shard_bounds(n, world, r) == (r * frame, (r + 1) * frame)

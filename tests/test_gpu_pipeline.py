@@ -235,3 +235,33 @@ def test_hit_integral_arithmetic_bitexact(gh, oracle, cuda):
     L.go_hit_integral_array(b2.ctypes.data, h.ctypes.data, n, ref.ctypes.data)
     bad = np.nonzero(got.view(np.uint32) != ref.view(np.uint32))[0]
     assert len(bad) == 0, (bad[:5], b2[bad[:5]], h[bad[:5]], got[bad[:5]], ref[bad[:5]])
+
+
+@pytest.mark.parametrize("n,n_rays", [(60000, 1024), (300000, 4096)])
+def test_packet_split_does_not_change_results(gh, oracle, cuda, n, n_rays):
+    """A packet walked by 1, 2, 4 or 8 waves (each owning 8/K of the summation classes)
+    gives bit-identical column densities and hit counts, equal to the oracle's class-ordered
+    sum / brute-force count."""
+    s = _spheres(oracle, n, (0, 0, 0, 0.005), (1, 1, 1, 0.04))
+    d, tree, ss, *_ = _build_both(gh, oracle, cuda, s, 32)
+    rays = gh.uniform_random_rays(n_rays, (0.5, 0.5, 0.5), 2.0, seed=5, device=cuda)
+    sub = np.linspace(0, n_rays - 1, 256).astype(np.int64)
+    ref32, ref64 = oracle.brute_cumulative(rays.cpu().numpy()[sub], ss)
+    refc = oracle.brute_hitcounts(rays.cpu().numpy()[sub], ss)
+    base_sum = base_cnt = None
+    try:
+        for k in (1, 2, 4, 8, -1):
+            gh.set_packet_split(k)
+            out = torch.empty(n_rays, dtype=torch.float32, device=cuda)
+            cnt = torch.empty(n_rays, dtype=torch.int32, device=cuda)
+            gh.trace_cumulative_sph(rays, d, tree, out)
+            gh.trace_hitcounts_sph(rays, d, tree, cnt)
+            gh.trace_status()
+            if base_sum is None:
+                base_sum, base_cnt = out.clone(), cnt.clone()
+                assert np.array_equal(out.cpu().numpy()[sub].view(np.uint32), ref32.view(np.uint32))
+                assert np.array_equal(cnt.cpu().numpy()[sub], refc)
+            assert torch.equal(out.view(torch.int32), base_sum.view(torch.int32)), k
+            assert torch.equal(cnt, base_cnt), k
+    finally:
+        gh.set_packet_split(-1)

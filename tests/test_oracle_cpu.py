@@ -189,3 +189,17 @@ def test_segscan_semantics(oracle):
     assert oracle.segscan(offs, data).tolist() == [0, 1, 3, 0, 4, 9, 15, 0]
     out, total = oracle.exclusive_scan_i32(np.array([3, 0, 4, 1], np.int32))
     assert out.tolist() == [0, 3, 3, 7] and total == 8
+
+
+def test_block_ordered_sum_vs_single_running_sum(oracle, gold):
+    """The stated result (8 interleaved primitive classes, summed pairwise) against the reference's
+    single fp32 running sum (blocks=1) and the fp64 sum: all within 1e-6."""
+    s = gold["spheres"]
+    _, ss, _ = oracle.sort_by_key(gold["keys30"], s)
+    ss = np.ascontiguousarray(ss)
+    c16, c64 = oracle.brute_cumulative(gold["rays"], ss)
+    c1, _ = oracle.brute_cumulative(gold["rays"], ss, blocks=1)
+    nz = c64 > 0
+    assert np.all(np.abs(c16[nz] - c64[nz]) <= 1e-6 * c64[nz])
+    assert np.all(np.abs(c1[nz] - c64[nz]) <= 1e-6 * c64[nz])
+    assert np.all(np.abs(c16[nz] - c1[nz]) <= 4e-7 * c64[nz])
