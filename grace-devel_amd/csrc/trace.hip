@@ -221,9 +221,26 @@ __device__ __forceinline__ float hit_integral(const float b2, const float ir, co
     return integral;
 }
 
+// The column-density trace's default evaluation of the same line integral (tolerance, not
+// bit, parity -- DESIGN.md section 4): v_sqrt_f32 as is (1 ulp), table position
+// b = sqrt(b2) * (50/h) with 50/h from the pre-pass, weight v_fract_f32(b), fp32 FMA on an
+// fp32 (y_i, y_{i+1} - y_i) table rounded from the fp64 one.  lutf has N_TABLE + 1 entries,
+// the last two being (y_50, 0), so b == 50 (sqrt(b2)/h rounded up to 1) needs no clamp.
+// Nine VALU instructions instead of twenty-five; each term within ~3 ulp of the exact one.
+__device__ __forceinline__ float hit_integral_fast(const float b2, const float ir50,
+                                                   const float ir2, const float2* lutf)
+{
+    const float b = __builtin_amdgcn_sqrtf(b2) * ir50;
+    const int x_idx = static_cast<int>(b);
+    const float t = __builtin_amdgcn_fractf(b);
+    const float2 y = lutf[x_idx];
+    return __builtin_fmaf(t, y.y, y.x) * ir2;
+}
+
 __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __restrict__ spheres,
                                                             size_t n, float4* __restrict__ A,
-                                                            float2* __restrict__ B)
+                                                            float2* __restrict__ B,
+                                                            const float b_scale)
 {
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n + 4;
          i += size_t(gridDim.x) * blockDim.x) {
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __rest
             a = make_float4(s.x, s.y, s.z, s.w * s.w); // sphere.w * sphere.w, intersect.h:37
             if (B) {
                 const float ir = 1.f / s.w;            // functors/trace.cuh:181
-                b = make_float2(ir, ir * ir);          // functors/trace.cuh:184
+                b = make_float2(ir * b_scale, ir * ir); // functors/trace.cuh:184 (b_scale 1, or 50: fast)
             }
         }
         A[i] = a;
@@ -483,20 +500,24 @@ __device__ __forceinline__ bool beam_may_hit(const float4 s, const Beam& bm)
     return !(b2_lo >= s.w);
 }
 
-template <int MODE, bool SPLIT>
+template <int MODE, bool SPLIT, bool FAST = false>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
 {
-    __shared__ double2 s_lut[N_TABLE];
+    static_assert(!FAST || MODE == MODE_CUMULATIVE, "only the column-density trace has a fast integral");
+    __shared__ double2 s_lut[FAST ? 1 : N_TABLE];
+    __shared__ float2 s_lutf[FAST ? N_TABLE + 1 : 1];
     // Per-wave tile of the candidates of the current culling round (MODE_TRI keeps its
     // fp64 triangles on the scalar path).
     constexpr bool LDS_TILE = (MODE != MODE_TRI);
     __shared__ float4 s_tileA[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 64 : 1];
     __shared__ float2 s_tileB[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 64 : 1];
     if (MODE == MODE_CUMULATIVE || MODE == MODE_HITS) {
-        if (threadIdx.x < N_TABLE) {
-            const double y0 = c_kernel_table[threadIdx.x];
-            const double y1 = threadIdx.x + 1 < N_TABLE ? c_kernel_table[threadIdx.x + 1] : y0;
-            s_lut[threadIdx.x] = make_double2(y0, y1 - y0);
+        if (threadIdx.x < N_TABLE + (FAST ? 1 : 0)) {
+            const int i0 = threadIdx.x < N_TABLE ? threadIdx.x : N_TABLE - 1;
+            const double y0 = c_kernel_table[i0];
+            const double y1 = i0 + 1 < N_TABLE ? c_kernel_table[i0 + 1] : y0;
+            if (FAST) s_lutf[threadIdx.x] = make_float2(float(y0), float(y1 - y0));
+            else s_lut[threadIdx.x] = make_double2(y0, y1 - y0);
         }
         __syncthreads();
     }
@@ -803,7 +824,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         if (MODE == MODE_COUNT || MODE == MODE_STATS) {
                             count += hit ? 1 : 0;
                         } else if (hit) {
-                            const float w = hit_integral(b2, curb.x, curb.y, s_lut);
+                            const float w = FAST ? hit_integral_fast(b2, curb.x, curb.y, s_lutf)
+                                                 : hit_integral(b2, curb.x, curb.y, s_lut);
                             if (MODE == MODE_CUMULATIVE) {
                                 sum += w;
                             } else if (valid) {
@@ -900,6 +922,7 @@ __global__ __launch_bounds__(256) void combine_classes_kernel(const float* __res
 }
 
 int g_split = -1; // waves per packet; -1: automatic
+bool g_exact_integrals = false; // column-density trace: bit-reproducible per-hit arithmetic
 
 template <int MODE>
 grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n_nodes,
@@ -959,7 +982,8 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                 reinterpret_cast<const float*>(a.spheres), n_spheres, A, T64);
         else
             trace_prepass_kernel<<<stream_grid(n_spheres + 4, 256), 256, 0, stream>>>(
-                a.spheres, n_spheres, A, B);
+                a.spheres, n_spheres, A, B,
+                (MODE == MODE_CUMULATIVE && !g_exact_integrals) ? float(N_TABLE - 1) : 1.0f);
         GRACE_CHECK_LAUNCH();
         a.A = A;
         a.B = B;
@@ -986,7 +1010,15 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         GRACE_TRY_HIP(hipEventRecord(g_ev0, stream));
     }
     const int grid = ceil_div(size_t(n_packets) * split, TRACE_BLOCK / 64);
-    if constexpr (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) {
+    if constexpr (MODE == MODE_CUMULATIVE) {
+        if (g_exact_integrals) {
+            if (split > 1) trace_kernel<MODE, true, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+            else trace_kernel<MODE, false, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        } else {
+            if (split > 1) trace_kernel<MODE, true, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+            else trace_kernel<MODE, false, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        }
+    } else if constexpr (MODE == MODE_COUNT) {
         if (split > 1) trace_kernel<MODE, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
         else trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
     } else {
@@ -1127,6 +1159,12 @@ grace_status grace_trace_set_packet_split(int waves_per_packet)
                       || waves_per_packet == 4 || waves_per_packet == 8,
                   "packet split must be 1, 2, 4, 8 or -1 (automatic)");
     g_split = waves_per_packet;
+    return GRACE_OK;
+}
+
+grace_status grace_trace_set_exact_integrals(int enabled)
+{
+    g_exact_integrals = enabled != 0;
     return GRACE_OK;
 }
 

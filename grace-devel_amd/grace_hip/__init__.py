@@ -265,6 +265,12 @@ def set_packet_split(k):
     _check(_lib.grace_trace_set_packet_split(C.c_int(int(k))))
 
 
+def set_exact_integrals(enabled):
+    """Column-density trace: True = the reference's per-hit arithmetic bit for bit (slower);
+    False (default) = hardware sqrt + fp32 table lerp (within the stated 1e-5 tolerance)."""
+    _check(_lib.grace_trace_set_exact_integrals(C.c_int(1 if enabled else 0)))
+
+
 def set_treelet_size(n):
     _check(_lib.grace_trace_set_treelet_size(C.c_int(int(n))))
 

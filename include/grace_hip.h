@@ -195,6 +195,15 @@ grace_status grace_trace_last_kernel_ms(float* h_ms);
  * depend on it (see csrc/trace.hip, "class-ordered sums and packet splitting"). */
 grace_status grace_trace_set_packet_split(int waves_per_packet);
 
+/* Column-density trace (grace_trace_cumulative_f4) only.  0 (default): each hit's kernel
+ * integral is evaluated with the hardware sqrt (1 ulp) and an fp32 table lerp -- within a few
+ * ulp of the reference arithmetic per term, column densities within 1e-6 of the fp64 sum
+ * (stated tolerance 1e-5).  1: the reference's arithmetic bit for bit (correctly rounded
+ * sqrt, fp64 lerp of the fp64 table; functors/trace.cuh:181-186, interpolate.h:11-39) --
+ * the result is then bit-identical to the CPU oracle's class-ordered sum, ~20 % slower.
+ * The per-hit outputs (grace_trace_hits_f4, grace_hit_integrals_f32) always use the latter. */
+grace_status grace_trace_set_exact_integrals(int enabled);
+
 /* Subtrees with at most this many primitives are swept in one culling pass instead of being
  * descended (results per ray unchanged).  0 disables; -1 (default) picks 512 when the call
  * has >= 4096 packets of 64 rays, else 256. */
