@@ -68,10 +68,10 @@
 //     waves, wave k owning the 8/K classes [k 8/K, (k+1) 8/K) -- a subtree of the summation
 //     tree, and, because classes interleave along the Morton order, an even share of the
 //     work for any beam -- with NO change of the result: each wave reduces its classes, a
-//     tiny kernel finishes the tree.  K is the smallest power of two that puts >= 32768 waves
-//     in flight (measured: K = 2 already helps the full 1024^2 image by evening out the
-//     packets' very different walk lengths; one eighth of the image on one of eight GPUs, or
-//     10^5 source rays, want K = 8: one wave per packet leaves the SIMDs idle there).  A wave
+//     tiny kernel finishes the tree.  K is the smallest power of two that puts >= 16384 waves
+//     in flight (measured: K = 1 for the full 1024^2 image; an eighth of it on one of eight
+//     GPUs runs 30 % faster with K = 2..8, and 10^5 isotropic source rays through 10^6 spheres
+//     3.6x faster with K = 8: one wave per packet leaves the SIMDs idle there).  A wave
 //     keeps its class accumulators in LDS (8 classes: 2 KiB per wave, so that LDS does not cap
 //     occupancy below the VGPR limit of 8 waves/SIMD) and switches at granule boundaries, once
 //     per culling round at most (the walk meets primitives in ascending order).  Hit counts
@@ -226,15 +226,16 @@ __device__ __forceinline__ float hit_integral(const float b2, const float ir, co
 // b = sqrt(b2) * (50/h) with 50/h from the pre-pass, weight v_fract_f32(b), fp32 FMA on an
 // fp32 (y_i, y_{i+1} - y_i) table rounded from the fp64 one.  lutf has N_TABLE + 1 entries,
 // the last two being (y_50, 0), so b == 50 (sqrt(b2)/h rounded up to 1) needs no clamp.
-// Nine VALU instructions instead of twenty-five; each term within ~3 ulp of the exact one.
+// Eight VALU instructions instead of twenty-five; each term within ~3 ulp of the exact one.
+// Returns the table value; the caller applies 1/h^2 inside its accumulating FMA.
 __device__ __forceinline__ float hit_integral_fast(const float b2, const float ir50,
-                                                   const float ir2, const float2* lutf)
+                                                   const float2* lutf)
 {
     const float b = __builtin_amdgcn_sqrtf(b2) * ir50;
     const int x_idx = static_cast<int>(b);
     const float t = __builtin_amdgcn_fractf(b);
     const float2 y = lutf[x_idx];
-    return __builtin_fmaf(t, y.y, y.x) * ir2;
+    return __builtin_fmaf(t, y.y, y.x);
 }
 
 __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __restrict__ spheres,
@@ -414,13 +415,16 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
         scale[k] = varies ? 1.0f / span : 0.f;
         nvar += varies ? 1 : 0;
     }
-    const int bits = nvar ? min(10, 30 / nvar) : 0;
+    const int bits = nvar ? min(15, 30 / nvar) : 0;
     const float qmax = float((1 << bits) - 1);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float* r = rays + 7 * size_t(i);
         uint32_t q[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) q[k] = uint32_t(fminf(qmax, (r[k] - lo[k]) * scale[k] * qmax));
+        // Round to nearest: a regular ray grid then maps to distinct, evenly spaced cells whatever
+        // the rounding of the scaling (a truncated 1023.9999 would merge two pixel columns and
+        // skew every 8x8 tile after it).
+        for (int k = 0; k < 6; ++k) q[k] = uint32_t(fminf(qmax, (r[k] - lo[k]) * scale[k] * qmax + 0.5f));
         uint32_t key = 0;
         for (int b = bits - 1; b >= 0; --b) {
 #pragma unroll
@@ -497,6 +501,22 @@ __device__ __forceinline__ bool beam_may_hit(const float4 s, const Beam& bm)
     }
     const float t2_hi = fmaxf(t_lo * t_lo, t_hi * t_hi);
     const float b2_lo = p2_lo - t2_hi - 3.814697265625e-06f * p2_hi; // 2^-18
+    return !(b2_lo >= s.w);
+}
+
+// Axis-aligned packet (every direction = +-e_AX): a ray's b2 is fl(fl(q1^2) + fl(q2^2)) with
+// q = fl(s - o) in the two perpendicular components.  Rounding is monotone, so replacing each
+// o by the point of the packet's origin interval nearest to s bounds every lane's b2 from
+// below EXACTLY -- no margin, eight instructions.
+template <int AX>
+__device__ __forceinline__ bool axis_beam_may_hit(const float4 s, const Beam& bm)
+{
+    constexpr int D1 = AX == 0 ? 1 : 0, D2 = AX == 2 ? 1 : 2;
+    const float s1 = AX == 0 ? s.y : s.x;
+    const float s2 = AX == 2 ? s.y : s.z;
+    const float q1 = s1 - __builtin_amdgcn_fmed3f(s1, bm.olo[D1], bm.ohi[D1]);
+    const float q2 = s2 - __builtin_amdgcn_fmed3f(s2, bm.olo[D2], bm.ohi[D2]);
+    const float b2_lo = q1 * q1 + q2 * q2;
     return !(b2_lo >= s.w);
 }
 
@@ -577,6 +597,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     // two perpendicular origins in component order.
     const float oa = axis == 0 ? ox : axis == 1 ? oy : oz;
     const float da = axis == 0 ? dx : axis == 1 ? dy : dz;
+    // (s_a - o_a) * d_a with d_a = +-1 is the correctly rounded +-(s_a - o_a): one FMA
+    // s_a * d_a + (-o_a * d_a) gives the same bits (both products are exact).
+    const float noda = -(oa * da);
     const float o1 = axis == 0 ? oy : ox;
     const float o2 = axis == 2 ? oy : oz;
 
@@ -677,14 +700,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             if (span.y <= a.treelet) {
                 sweep = true; sweep_first = span.x; sweep_count = span.y;
             } else {
+            // (A wave-uniform box-overlap test of the packet's bounding box -- twelve compares
+            // instead of this per-ray slab test -- was tried for axis-aligned packets: same node
+            // count, 25 % SLOWER kernel; node tests are only ~320 per packet, 6 % of the VALU work.)
             const int lr = aabbs_hit(ix, iy, iz, ox, oy, oz, len, L, R, Z);
             const bool hit_r = lr & 1, hit_l = lr >= 2;
+            const unsigned long long vote_r = __builtin_amdgcn_ballot_w64(hit_r);
+            const unsigned long long vote_l = __builtin_amdgcn_ballot_w64(hit_l);
 #ifdef GRACE_PACKET_STATS
 #else
             if (MODE == MODE_STATS && alive) ++st_nodes;
 #endif
-            const unsigned long long vote_r = __builtin_amdgcn_ballot_w64(hit_r);
-            const unsigned long long vote_l = __builtin_amdgcn_ballot_w64(hit_l);
             if (vote_r) push(__float_as_int(n0.y),
                              MODE == MODE_STATS ? __builtin_amdgcn_ballot_w64(hit_r && alive) : 0ull);
             if (vote_l) push(__float_as_int(n0.x),
@@ -731,7 +757,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     mine_next = pa[nj < leaf.y ? nj : base + 64];
                     if (LDS_TILE && NEED_B) mineb_next = pb[nj < leaf.y ? nj : base + 64];
                 }
-                const bool keep = lane < m && beam_may_hit(mine, beam);
+                bool keep;
+                if constexpr (AX >= 0) keep = lane < m && axis_beam_may_hit<AX>(mine, beam);
+                else keep = lane < m && beam_may_hit(mine, beam);
                 unsigned long long rest = __builtin_amdgcn_ballot_w64(keep);
 #ifdef GRACE_PACKET_STATS
                 if (MODE == MODE_STATS) { st_leaves += 1; st_tested += __builtin_popcountll(rest); }
@@ -763,42 +791,18 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     if (CLASSES && pf >= cur_granule_end) enter_granule(pf); // ascending index
                     if (SPLIT && !(CLASSES ? cur_owned : owns_granule(pf >> GRANULE_SHIFT))) continue;
                 }
-                int j = base + __builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                float4 cur;
-                float2 curb = make_float2(0.f, 0.f);
-                if (LDS_TILE) {
-                    cur = s_tileA[wv][j - base];
-                    if (NEED_B) curb = s_tileB[wv][j - base];
-                } else {
-                    cur = pa[j];
-                }
-                for (;;) {
-                    const bool more = todo != 0ull;
-                    int jn = 0;
-                    float4 nxt4 = cur;
-                    float2 nxtb = curb;
-                    if (more) { // issue the next survivor's loads before the math
-                        jn = base + __builtin_ctzll(todo);
-                        todo &= todo - 1ull;
-                        if (LDS_TILE) {
-                            nxt4 = s_tileA[wv][jn - base];
-                            if (NEED_B) nxtb = s_tileB[wv][jn - base];
-                        } else {
-                            nxt4 = pa[jn];
-                        }
-                    }
+                // One survivor: the packet's 64 rays against candidate jj (wave-uniform).
+                auto process = [&](const float4 s, const float2 sb, const int jj) {
                     if (MODE == MODE_TRI) {
                         // RayIntersect_tri + OnHit_tri (tris_trace.cuh:24-61)
                         float t;
-                        if (tri_intersect(ddx, ddy, ddz, ox, oy, oz, a.T64 + 9 * size_t(leaf.x + j), &t)) {
+                        if (tri_intersect(ddx, ddy, ddz, ox, oy, oz, a.T64 + 9 * size_t(leaf.x + jj), &t)) {
                             if (t <= tri_tmin && t >= 1E-14f) {
                                 tri_tmin = t;
-                                tri_data = leaf.x + j;
+                                tri_data = leaf.x + jj;
                             }
                         }
                     } else {
-                        const float4 s = cur;
                         float b2, dot_p;
                         if (AX >= 0) {
                             // sphere_hit collapsed for d = +-e_AX (see the file header)
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                             const float s1 = AX == 0 ? s.y : s.x;
                             const float s2 = AX == 2 ? s.y : s.z;
                             const float q1 = s1 - o1, q2 = s2 - o2;
-                            dot_p = (sa - oa) * da;
+                            dot_p = __builtin_fmaf(sa, da, noda);
                             b2 = q1 * q1 + q2 * q2;
                         } else {
                             // sphere_hit, include/grace/generic/intersect.h:16-54; s.w = h*h
@@ -824,18 +828,46 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         if (MODE == MODE_COUNT || MODE == MODE_STATS) {
                             count += hit ? 1 : 0;
                         } else if (hit) {
-                            const float w = FAST ? hit_integral_fast(b2, curb.x, curb.y, s_lutf)
-                                                 : hit_integral(b2, curb.x, curb.y, s_lut);
-                            if (MODE == MODE_CUMULATIVE) {
+                            const float w = FAST ? hit_integral_fast(b2, sb.x, s_lutf)
+                                                 : hit_integral(b2, sb.x, sb.y, s_lut);
+                            if (FAST) {
+                                sum = __builtin_fmaf(w, sb.y, sum);
+                            } else if (MODE == MODE_CUMULATIVE) {
                                 sum += w;
                             } else if (valid) {
-                                a.hit_idx[write_at] = leaf.x + j;
+                                a.hit_idx[write_at] = leaf.x + jj;
                                 a.hit_integral[write_at] = w;
                                 a.hit_dist[write_at] = dot_p;
                                 ++write_at;
                             }
                         }
                     }
+                };
+                // Fetch the next survivor (lowest set bit of `todo`) from the wave's LDS tile.
+                auto fetch = [&](float4& c, float2& cb, int& jj) {
+                    jj = base + __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    if (LDS_TILE) {
+                        c = s_tileA[wv][jj - base];
+                        if (NEED_B) cb = s_tileB[wv][jj - base];
+                    } else {
+                        c = pa[jj];
+                    }
+                };
+                // One survivor ahead: the next one's LDS reads are issued before this one's
+                // math.  (Alternating between two register sets instead of copying was measured
+                // 2 % slower: the compiler's in-order lgkmcnt waits then expose the new reads.)
+                float4 cur;
+                float2 curb = make_float2(0.f, 0.f);
+                int j;
+                fetch(cur, curb, j);
+                for (;;) {
+                    const bool more = todo != 0ull;
+                    float4 nxt4 = cur;
+                    float2 nxtb = curb;
+                    int jn = 0;
+                    if (more) fetch(nxt4, nxtb, jn);
+                    process(cur, curb, j);
                     if (!more) break;
                     cur = nxt4;
                     curb = nxtb;
@@ -992,11 +1024,11 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     a.n_nodes = int(n_nodes);
     a.status = g_status;
     const int n_packets = ceil_div(n_rays, 64);
-    // Waves per packet: enough waves to fill the chip (8192 resident) for small ray batches.
+    // Waves per packet: two resident sets of waves (2 x 8192) for small ray batches.
     int split = 1;
     if (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) {
         if (g_split > 0) split = g_split;
-        else while (split < SUM_CLASSES && size_t(n_packets) * split < 32768) split *= 2;
+        else while (split < SUM_CLASSES && size_t(n_packets) * split < 16384) split *= 2;
     }
     a.split = split;
     a.n_prims = int(n_spheres);
