@@ -600,6 +600,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     // (s_a - o_a) * d_a with d_a = +-1 is the correctly rounded +-(s_a - o_a): one FMA
     // s_a * d_a + (-o_a * d_a) gives the same bits (both products are exact).
     const float noda = -(oa * da);
+    // For the range-check-free sweep (below): the packet's extremes of -o_a d_a and of the ray
+    // length, and whether all rays point the same way along the axis.
+    float noda_lo = 0.f, noda_hi = 0.f, len_lo = 0.f, da0 = 0.f;
+    bool same_sense = false;
+    if (axis >= 0) {
+        noda_lo = wave_min(noda); noda_hi = wave_max(noda); len_lo = wave_min(len);
+        const unsigned long long fwd = __builtin_amdgcn_ballot_w64(da > 0.f);
+        same_sense = fwd == 0ull || fwd == ~0ull;
+        da0 = fwd ? 1.f : -1.f;
+    }
     const float o1 = axis == 0 ? oy : ox;
     const float o2 = axis == 2 ? oy : oz;
 
@@ -760,6 +770,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                 bool keep;
                 if constexpr (AX >= 0) keep = lane < m && axis_beam_may_hit<AX>(mine, beam);
                 else keep = lane < m && beam_may_hit(mine, beam);
+                // Axis packets: if every kept candidate lies inside every ray's [0, length)
+                // along the axis -- decided per candidate with the same FMA the rays use, which
+                // is monotone in its addend -- the round's survivors skip the two range tests.
+                bool lean_round = false;
+                if constexpr (AX >= 0 && (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE)) {
+                    const float sa = AX == 0 ? mine.x : AX == 1 ? mine.y : mine.z;
+                    const bool inside = __builtin_fmaf(sa, da0, noda_lo) >= 0.0f
+                                     && __builtin_fmaf(sa, da0, noda_hi) < len_lo;
+                    lean_round = same_sense && __builtin_amdgcn_ballot_w64(keep && !inside) == 0ull;
+                }
                 unsigned long long rest = __builtin_amdgcn_ballot_w64(keep);
 #ifdef GRACE_PACKET_STATS
                 if (MODE == MODE_STATS) { st_leaves += 1; st_tested += __builtin_popcountll(rest); }
@@ -792,7 +812,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     if (SPLIT && !(CLASSES ? cur_owned : owns_granule(pf >> GRANULE_SHIFT))) continue;
                 }
                 // One survivor: the packet's 64 rays against candidate jj (wave-uniform).
-                auto process = [&](const float4 s, const float2 sb, const int jj) {
+                auto process = [&](auto lean_tag, const float4 s, const float2 sb, const int jj) {
+                    constexpr bool LEAN = decltype(lean_tag)::value;
                     if (MODE == MODE_TRI) {
                         // RayIntersect_tri + OnHit_tri (tris_trace.cuh:24-61)
                         float t;
@@ -810,7 +831,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                             const float s1 = AX == 0 ? s.y : s.x;
                             const float s2 = AX == 2 ? s.y : s.z;
                             const float q1 = s1 - o1, q2 = s2 - o2;
-                            dot_p = __builtin_fmaf(sa, da, noda);
+                            dot_p = LEAN ? 0.0f : __builtin_fmaf(sa, da, noda);
                             b2 = q1 * q1 + q2 * q2;
                         } else {
                             // sphere_hit, include/grace/generic/intersect.h:16-54; s.w = h*h
@@ -821,7 +842,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                             const float bz = pz - dot_p * dz;
                             b2 = bx * bx + by * by + bz * bz;
                         }
-                        const bool hit = !(b2 >= s.w) && !(dot_p < 0.0f) && !(dot_p >= len);
+                        const bool hit = LEAN ? !(b2 >= s.w)
+                                              : !(b2 >= s.w) && !(dot_p < 0.0f) && !(dot_p >= len);
 #ifdef GRACE_PACKET_STATS
                         if (MODE == MODE_STATS && __builtin_amdgcn_ballot_w64(hit) != 0ull) ++st_nodes;
 #endif
@@ -854,25 +876,26 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         c = pa[jj];
                     }
                 };
-                // One survivor ahead: the next one's LDS reads are issued before this one's
-                // math.  (Alternating between two register sets instead of copying was measured
-                // 2 % slower: the compiler's in-order lgkmcnt waits then expose the new reads.)
-                float4 cur;
-                float2 curb = make_float2(0.f, 0.f);
-                int j;
-                fetch(cur, curb, j);
-                for (;;) {
-                    const bool more = todo != 0ull;
-                    float4 nxt4 = cur;
-                    float2 nxtb = curb;
-                    int jn = 0;
-                    if (more) fetch(nxt4, nxtb, jn);
-                    process(cur, curb, j);
-                    if (!more) break;
-                    cur = nxt4;
-                    curb = nxtb;
-                    j = jn;
-                }
+                // One survivor ahead, alternating between two register sets: each is loaded
+                // while the other is being processed, so no copies sit between survivors.
+                auto run = [&](auto lean_tag) {
+                    float4 c0, c1;
+                    float2 b0 = make_float2(0.f, 0.f), b1 = make_float2(0.f, 0.f);
+                    int j0, j1 = 0;
+                    fetch(c0, b0, j0);
+                    for (;;) {
+                        bool more = todo != 0ull;
+                        if (more) fetch(c1, b1, j1);
+                        process(lean_tag, c0, b0, j0);
+                        if (!more) break;
+                        more = todo != 0ull;
+                        if (more) fetch(c0, b0, j0);
+                        process(lean_tag, c1, b1, j1);
+                        if (!more) break;
+                    }
+                };
+                if (lean_round) run(std::true_type());
+                else run(std::false_type());
                 } // granule chunks of the round
             }
             };

@@ -205,6 +205,14 @@ def brute_cumulative(rays, prims, blocks=SUM_BLOCKS):
     return out, out64
 
 
+def kernel_table():
+    """The 51-entry line-integral table (kernel_integrals.h) as float64."""
+    n = C.c_int(0)
+    lib().go_kernel_table.restype = C.POINTER(C.c_double)
+    ptr = lib().go_kernel_table(C.byref(n))
+    return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+
 def brute_hits(rays, prims):
     """Returns offsets (exclusive), idx, integrals, distances -- trace_sph contract."""
     counts = brute_hitcounts(rays, prims)

@@ -37,16 +37,24 @@ def integral_mode(request, gh):
     gh.set_exact_integrals(False)
 
 
-def check_column_densities(got, ref32, ref64, mode):
+def check_column_densities(got, ref32, ref64, mode, max_term=None):
     """got: traced column densities; ref32 / ref64: the oracle's class-ordered fp32 sum and its
-    fp64 sum.  Stated tolerance 1e-5 in both modes; "exact" is bit-identical to
-    the oracle, "fast" stays within 3e-6 (measured: 2.4e-7 from exact at 10^7 particles)."""
+    fp64 sum.  Stated tolerance 1e-5 relative in both modes; "exact" is
+    bit-identical to the oracle, "fast" stays within 3e-6 (measured: 2.4e-7 from exact at 10^7
+    particles).  max_term: for rays that may consist of a few grazing hits only (short
+    segments), the largest single term F(0)/h_min^2 -- the fast evaluation's error is a few
+    ulp of the TABLE POSITION, i.e. absolute ~1e-6 of the table's scale per hit, which no
+    relative bound on a near-zero sum can express."""
     import numpy as np
-    assert np.allclose(got, ref64, rtol=1e-5, atol=0)
+    atol = 0.0 if max_term is None else 2e-6 * max_term
+    err = np.abs(got - ref64)
+    bad = np.nonzero(err > 1e-5 * np.abs(ref64) + atol)[0]
+    assert len(bad) == 0, (bad[:5], got[bad[:5]], ref64[bad[:5]])
     if mode == "exact":
         assert np.array_equal(got.view(np.uint32), ref32.view(np.uint32))
     else:
-        assert np.allclose(got, ref64, rtol=3e-6, atol=0)
+        bad = np.nonzero(err > 3e-6 * np.abs(ref64) + atol)[0]
+        assert len(bad) == 0, (bad[:5], got[bad[:5]], ref64[bad[:5]])
 
 
 @pytest.fixture(scope="session")
