@@ -529,8 +529,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     // Per-wave tile of the candidates of the current culling round (MODE_TRI keeps its
     // fp64 triangles on the scalar path).
     constexpr bool LDS_TILE = (MODE != MODE_TRI);
-    __shared__ float4 s_tileA[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 64 : 1];
-    __shared__ float2 s_tileB[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 64 : 1];
+    // Three 8-byte planes per wave -- (x, y), (z, h^2), (1/h terms) -- so that one address
+    // (plane base + 8 j) serves all of a survivor's reads through immediate offsets.
+    // (66 slots: the survivor loop reads up to two slots past the round's last survivor)
+    __shared__ float2 s_tile[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 3 : 1][LDS_TILE ? 66 : 1];
     if (MODE == MODE_CUMULATIVE || MODE == MODE_HITS) {
         if (threadIdx.x < N_TABLE + (FAST ? 1 : 0)) {
             const int i0 = threadIdx.x < N_TABLE ? threadIdx.x : N_TABLE - 1;
@@ -786,12 +788,25 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
 #endif
                 if (rest == 0ull) continue;
                 const int wv = threadIdx.x >> 6;
+                // Hit counts and column densities need no candidate index: their tile holds the
+                // survivors only, in ascending order (slot = number of kept lanes below), so the
+                // k-th survivor sits at slot k -- no bit scanning, and slot addresses that differ
+                // by immediates.  The per-hit and triangle modes keep lane-indexed tiles.
+                constexpr bool COMPACT = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE);
                 if (LDS_TILE) {
                     // Stage the round's candidates; survivors are then broadcast-read from LDS
                     // into VGPRs (in-order LDS returns, no scalar-load round trips, VGPR operands).
-                    s_tileA[wv][lane] = mine;
-                    if (NEED_B) s_tileB[wv][lane] = mineb;
+                    const int slot = COMPACT
+                        ? int(__builtin_amdgcn_mbcnt_hi(uint32_t(rest >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo(uint32_t(rest), 0u)))
+                        : lane;
+                    if (!COMPACT || keep) {
+                        s_tile[wv][0][slot] = make_float2(mine.x, mine.y);
+                        s_tile[wv][LDS_TILE ? 1 : 0][slot] = make_float2(mine.z, mine.w);
+                        if (NEED_B) s_tile[wv][LDS_TILE ? 2 : 0][slot] = mineb;
+                    }
                 }
+                int next_slot = 0; // COMPACT: survivors of this round consumed so far
                 // The round's survivors are taken granule by granule (a round of 64 consecutive
                 // primitives touches at most two), so that the class accumulator switch and the
                 // ownership test of a split packet stay out of the per-survivor loop.
@@ -809,7 +824,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         todo &= below;
                     }
                     if (CLASSES && pf >= cur_granule_end) enter_granule(pf); // ascending index
-                    if (SPLIT && !(CLASSES ? cur_owned : owns_granule(pf >> GRANULE_SHIFT))) continue;
+                    if (SPLIT && !(CLASSES ? cur_owned : owns_granule(pf >> GRANULE_SHIFT))) {
+                        next_slot += __builtin_popcountll(todo);
+                        continue;
+                    }
                 }
                 // One survivor: the packet's 64 rays against candidate jj (wave-uniform).
                 auto process = [&](auto lean_tag, const float4 s, const float2 sb, const int jj) {
@@ -865,33 +883,55 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         }
                     }
                 };
-                // Fetch the next survivor (lowest set bit of `todo`) from the wave's LDS tile.
-                auto fetch = [&](float4& c, float2& cb, int& jj) {
-                    jj = base + __builtin_ctzll(todo);
-                    todo &= todo - 1ull;
+                // Fetch a survivor from the wave's LDS tile: slot k of the compacted tile, or the
+                // lowest set bit of `td` (which always carries bit 63 as a sentinel) otherwise.
+                // Issued UNCONDITIONALLY, up to two past the last survivor: lgkmcnt counts in
+                // order, so a fetch on only one of two merging paths makes the compiler wait for
+                // everything outstanding -- the just-issued reads included -- before each test.
+                auto fetch = [&](unsigned long long& td, int& k, float4& c, float2& cb, int& jj) {
+                    int at;
+                    if (COMPACT) {
+                        at = k++;
+                        jj = 0;
+                    } else {
+                        at = __builtin_ctzll(td);
+                        td = (td & ~(1ull << at)) | 0x8000000000000000ull;
+                        jj = base + at;
+                    }
                     if (LDS_TILE) {
-                        c = s_tileA[wv][jj - base];
-                        if (NEED_B) cb = s_tileB[wv][jj - base];
+                        const float2 xy = s_tile[wv][0][at];
+                        const float2 zw = s_tile[wv][LDS_TILE ? 1 : 0][at];
+                        c = make_float4(xy.x, xy.y, zw.x, zw.y);
+                        if (NEED_B) cb = s_tile[wv][LDS_TILE ? 2 : 0][at];
+                        // Keep the reads here -- ahead of the survivors in between -- instead of
+                        // letting the scheduler sink them next to their use.
+                        __builtin_amdgcn_sched_barrier(0);
                     } else {
                         c = pa[jj];
                     }
                 };
-                // One survivor ahead, alternating between two register sets: each is loaded
-                // while the other is being processed, so no copies sit between survivors.
                 auto run = [&](auto lean_tag) {
-                    float4 c0, c1;
-                    float2 b0 = make_float2(0.f, 0.f), b1 = make_float2(0.f, 0.f);
-                    int j0, j1 = 0;
-                    fetch(c0, b0, j0);
+                    // Two survivors ahead, rotating through three register sets: each is loaded
+                    // while the other two are being processed; no copies between survivors.
+                    float4 c0, c1, c2;
+                    float2 b0 = make_float2(0.f, 0.f), b1 = b0, b2 = b0;
+                    int j0, j1 = 0, j2 = 0;
+                    int left = __builtin_popcountll(todo);
+                    unsigned long long td = todo | 0x8000000000000000ull;
+                    int k = next_slot;
+                    next_slot += left;
+                    fetch(td, k, c0, b0, j0);
+                    fetch(td, k, c1, b1, j1);
                     for (;;) {
-                        bool more = todo != 0ull;
-                        if (more) fetch(c1, b1, j1);
+                        fetch(td, k, c2, b2, j2);
                         process(lean_tag, c0, b0, j0);
-                        if (!more) break;
-                        more = todo != 0ull;
-                        if (more) fetch(c0, b0, j0);
+                        if (--left == 0) break;
+                        fetch(td, k, c0, b0, j0);
                         process(lean_tag, c1, b1, j1);
-                        if (!more) break;
+                        if (--left == 0) break;
+                        fetch(td, k, c1, b1, j1);
+                        process(lean_tag, c2, b2, j2);
+                        if (--left == 0) break;
                     }
                 };
                 if (lean_round) run(std::true_type());
