@@ -213,6 +213,15 @@ def main():
             except Exception:
                 traffic = None
         img = image[:frame_rays]   # frame 0
+        # Compulsory bytes: everything the launch must read at least once --
+        # the pre-pass records of all particles (16 + 8 B), every node (64 B + 8 B span) and
+        # leaf (16 B), this rank's rays (28 B) -- plus 4 B written per ray.
+        compulsory = (24 * n + 72 * (tree.n_leaves - 1) + 16 * tree.n_leaves
+                      + 32 * (n_rays // world))
+        measured = None
+        if traffic:
+            measured = {"GB/s": round(traffic / (kern_ms * 1e-3) / 1e9, 1),
+                        "frac_of_peak": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         out = {
             "metric": "Mrays/s SPH column-density trace, 10^7 particles",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
@@ -233,6 +242,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_ms": round(kern_ms, 4), "call_ms": round(call_ms, 4),
                          "algorithmic_bytes_per_launch": int(alg_per_launch),
+                         "compulsory_bytes_per_launch": int(compulsory),
+                         "measured_hbm": measured,
                          "per_ray_mean": {"nodes": nodes_v / n_rays, "leaves": leaves_v / n_rays,
                                           "spheres_tested": tested / n_rays,
                                           "hits": hits / n_rays}},
