@@ -172,6 +172,53 @@ grace_status morton_keys(const float* d_spheres, size_t n, const Real* bot, cons
     return GRACE_OK;
 }
 
+// Generic points: n records of `stride` Elem each, x y z first (float3, float4, double3,
+// double4).  CentroidSphere (generic/functors/centroid.h:33-40) narrows the co-ordinates to
+// float BEFORE the key arithmetic, for double input too -- tests/morton_key_kernel/
+// 63bit_keys.cu:52-58 spells out that the host must cast to match.
+template <typename Key, typename Elem>
+__global__ __launch_bounds__(256) void morton_keys_points_kernel(const Elem* __restrict__ pts,
+                                                                 size_t n, int stride, float minx,
+                                                                 float miny, float minz, float sx,
+                                                                 float sy, float sz,
+                                                                 Key* __restrict__ keys)
+{
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x) {
+        const Elem* q = pts + i * size_t(stride);
+        const float cx = static_cast<float>(q[0]), cy = static_cast<float>(q[1]),
+                    cz = static_cast<float>(q[2]);
+        const Key x = static_cast<Key>(sx * (cx - minx));
+        const Key y = static_cast<Key>(sy * (cy - miny));
+        const Key z = static_cast<Key>(sz * (cz - minz));
+        keys[i] = Interleave<Key>::key(x, y, z);
+    }
+}
+
+template <typename Key>
+grace_status morton_keys_points(const void* d_points, size_t n, int is_double, int stride,
+                                const float* bot, const float* top, Key* d_keys,
+                                hipStream_t stream)
+{
+    GRACE_REQUIRE(d_points && d_keys && bot && top, "morton_keys (points): null pointer");
+    GRACE_REQUIRE(stride >= 3 && stride <= 16, "morton_keys (points): elements per point must be 3..16");
+    if (n == 0) return GRACE_OK;
+    const int span = sizeof(Key) > 4 ? (1u << 21) - 1 : (1u << 10) - 1;
+    const float sx = span / (top[0] - bot[0]);
+    const float sy = span / (top[1] - bot[1]);
+    const float sz = span / (top[2] - bot[2]);
+    if (is_double)
+        morton_keys_points_kernel<Key, double><<<stream_grid(n, 256), 256, 0, stream>>>(
+            static_cast<const double*>(d_points), n, stride, bot[0], bot[1], bot[2], sx, sy, sz,
+            d_keys);
+    else
+        morton_keys_points_kernel<Key, float><<<stream_grid(n, 256), 256, 0, stream>>>(
+            static_cast<const float*>(d_points), n, stride, bot[0], bot[1], bot[2], sx, sy, sz,
+            d_keys);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
 // ---- triangle primitives: {v, e1, e2}, 9 floats (tests/profile_trace_triangle/triangle.cuh:11-25)
 // TriangleCentroid (triangle.cuh:92-102): v + (1./3.) * (e1 + e2), all fp32 (the scalar binds
 // to operator*(float, float3), tests/helper/vector_math.cuh:34-37).
@@ -307,6 +354,22 @@ grace_status grace_morton_keys63_f4_d3(const float* d_spheres, size_t n, const d
                                        grace_stream stream)
 {
     return morton_keys<uint64_t, double>(d_spheres, n, h_bot, h_top, d_keys, as_stream(stream));
+}
+
+grace_status grace_morton_keys30_points(const void* d_points, size_t n, int is_double,
+                                        int elems_per_point, const float* h_bot,
+                                        const float* h_top, uint32_t* d_keys, grace_stream stream)
+{
+    return morton_keys_points<uint32_t>(d_points, n, is_double, elems_per_point, h_bot, h_top,
+                                        d_keys, as_stream(stream));
+}
+
+grace_status grace_morton_keys63_points(const void* d_points, size_t n, int is_double,
+                                        int elems_per_point, const float* h_bot,
+                                        const float* h_top, uint64_t* d_keys, grace_stream stream)
+{
+    return morton_keys_points<uint64_t>(d_points, n, is_double, elems_per_point, h_bot, h_top,
+                                        d_keys, as_stream(stream));
 }
 
 } // extern "C"

@@ -461,6 +461,78 @@ def uniform_random_rays(n_rays, origin, length, seed=1234, device="cuda"):
     return rays
 
 
+# enum Octants / enum RaySortType, grace/types.h:36-51
+PPP, PPM, PMP, PMM, MPP, MPM, MMP, MMM = 7, 6, 5, 4, 3, 2, 1, 0
+NoSort, DirectionSort, EndPointSort = 0, 1, 2
+
+
+def uniform_random_rays_single_octant(n_rays, origin, length, octant=PPP, seed=1234, device="cuda"):
+    """gen_rays.cuh:62-97: isotropic directions confined to one octant, direction-sorted."""
+    rays = torch.empty((n_rays, RAY_FLOATS), dtype=torch.float32, device=device)
+    _check(_lib.grace_rays_isotropic_octant(C.c_size_t(n_rays), C.c_float(origin[0]),
+                                            C.c_float(origin[1]), C.c_float(origin[2]),
+                                            C.c_float(length), C.c_int(int(octant)),
+                                            C.c_uint64(seed), _ptr(rays), _stream()))
+    return rays
+
+
+def _points(points):
+    assert points.is_contiguous() and points.dim() == 2 and 3 <= points.shape[1] <= 16
+    assert points.dtype in (torch.float32, torch.float64)
+    return C.c_int(1 if points.dtype == torch.float64 else 0), C.c_int(points.shape[1])
+
+
+def one_to_many_rays(origin, points, sort_type=DirectionSort, bot=None, top=None):
+    """gen_rays.cuh:99-208: one ray from `origin` to each point ([n, 3..] float32/float64).
+    EndPointSort needs the points' bounds (computed here when not given -- the reference's
+    bounds-free overload passes AABB_bot twice, which is not reproduced)."""
+    isd, k = _points(points)
+    rays = torch.empty((len(points), RAY_FLOATS), dtype=torch.float32, device=points.device)
+    b = t = None
+    if sort_type == EndPointSort:
+        if bot is None:
+            bot = points[:, :3].min(dim=0).values.float().tolist()
+            top = points[:, :3].max(dim=0).values.float().tolist()
+        b = (C.c_float * 3)(*[float(x) for x in bot]); t = (C.c_float * 3)(*[float(x) for x in top])
+    _check(_lib.grace_rays_one_to_many(C.c_size_t(len(points)), C.c_float(origin[0]),
+                                       C.c_float(origin[1]), C.c_float(origin[2]), _ptr(points),
+                                       isd, k, C.c_int(int(sort_type)), b, t, _ptr(rays), _stream()))
+    return rays
+
+
+def plane_parallel_random_rays(width, height, base, w, h, length, seed=1234, device="cuda"):
+    """gen_rays.cuh:210-262: one ray per cell of the width x height grid spanned by w, h."""
+    rays = torch.empty((width * height, RAY_FLOATS), dtype=torch.float32, device=device)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    _check(_lib.grace_rays_plane_parallel_random(C.c_int(width), C.c_int(height), f3(base), f3(w),
+                                                 f3(h), C.c_float(length), C.c_uint64(seed),
+                                                 _ptr(rays), _stream()))
+    return rays
+
+
+def orthographic_projection_rays(res_x, res_y, camera, look_at, view_up, vertical_extent, length,
+                                 device="cuda"):
+    """gen_rays.cuh:264-329."""
+    rays = torch.empty((res_x * res_y, RAY_FLOATS), dtype=torch.float32, device=device)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    _check(_lib.grace_rays_orthographic_projection(C.c_int(res_x), C.c_int(res_y), f3(camera),
+                                                   f3(look_at), f3(view_up),
+                                                   C.c_float(vertical_extent), C.c_float(length),
+                                                   _ptr(rays), _stream()))
+    return rays
+
+
+def morton_keys_points(points, keys, bot, top):
+    """morton_keys over float3/float4/double3/double4 points (build_sph.cuh:16-33 with
+    Real4 = double4; tests/morton_key_kernel/63bit_keys.cu): co-ordinates narrowed to float
+    first.  keys.dtype int32 -> 30-bit, int64 -> 63-bit."""
+    isd, k = _points(points)
+    b = (C.c_float * 3)(*[float(x) for x in bot]); t = (C.c_float * 3)(*[float(x) for x in top])
+    fn = _lib.grace_morton_keys30_points if keys.dtype == torch.int32 else _lib.grace_morton_keys63_points
+    _check(fn(_ptr(points), C.c_size_t(len(points)), isd, k, b, t, _ptr(keys), _stream()))
+    return keys
+
+
 def project_sph(spheres, n_side, max_per_leaf=32):
     """The projection of tests/project_gadget/project_gadget.cu:58-81: bounds with
     w = 0, build_tree, orthogonal_rays_z, trace_cumulative_sph.  Sorts spheres in place.

@@ -37,6 +37,12 @@ typedef uint64_t uinteger64;
 struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
 struct int4 { int x, y, z, w; };
+struct double3 { double x, y, z; };
+struct double4 { double x, y, z, w; };
+
+// include/grace/types.h:36-51
+enum Octants { PPP = 7, PPM = 6, PMP = 5, PMM = 4, MPP = 3, MPM = 2, MMP = 1, MMM = 0 };
+enum RaySortType { NoSort, DirectionSort, EndPointSort };
 
 inline float3 make_float3(float x, float y, float z) { float3 v = { x, y, z }; return v; }
 inline float4 make_float4(float x, float y, float z, float w) { float4 v = { x, y, z, w }; return v; }
@@ -391,6 +397,145 @@ inline void sort_by_distance(device_vector<float>& d_hit_distances,
     detail::check(grace_sort_by_distance_f32(d_hit_distances.data(), d_ray_offsets.data(),
                                              d_ray_offsets.size(), d_hit_distances.size(),
                                              d_hit_indices.data(), d_hit_data.data(), nullptr));
+}
+
+// ---- ray generators, include/grace/cuda/gen_rays.cuh (vector overloads: d_rays is grown when
+// too small, never shrunk).  Random generators use this library's own counter-based streams;
+// the reference's cuRAND streams are device-specific by its own account (gen_rays.cuh:21-24).
+namespace detail {
+template <typename T> struct point_traits;   // PointType: any of the four below
+template <> struct point_traits<float3> { enum { is_double = 0, elems = 3 }; };
+template <> struct point_traits<float4> { enum { is_double = 0, elems = 4 }; };
+template <> struct point_traits<double3> { enum { is_double = 1, elems = 3 }; };
+template <> struct point_traits<double4> { enum { is_double = 1, elems = 4 }; };
+} // namespace detail
+
+// gen_rays.cuh:25-60
+inline void uniform_random_rays(device_vector<Ray>& d_rays, const float ox, const float oy,
+                                const float oz, const float length,
+                                const unsigned long long seed = 1234)
+{
+    detail::check(grace_rays_isotropic(d_rays.size(), ox, oy, oz, length, seed, d_rays.data(),
+                                       nullptr));
+}
+
+// gen_rays.cuh:62-97
+inline void uniform_random_rays_single_octant(device_vector<Ray>& d_rays, const float ox,
+                                              const float oy, const float oz, const float length,
+                                              const enum Octants octant = PPP,
+                                              const unsigned long long seed = 1234)
+{
+    detail::check(grace_rays_isotropic_octant(d_rays.size(), ox, oy, oz, length, int(octant), seed,
+                                              d_rays.data(), nullptr));
+}
+
+// gen_rays.cuh:161-208 (bounds known) -- end-point sort.
+template <typename PointType>
+inline void one_to_many_rays(device_vector<Ray>& d_rays, const float ox, const float oy,
+                             const float oz, const device_vector<PointType>& d_points,
+                             const float3 AABB_bot, const float3 AABB_top)
+{
+    if (d_rays.size() < d_points.size()) d_rays.resize(d_points.size());
+    detail::check(grace_rays_one_to_many(d_points.size(), ox, oy, oz, d_points.data(),
+                                         detail::point_traits<PointType>::is_double,
+                                         detail::point_traits<PointType>::elems, int(EndPointSort),
+                                         &AABB_bot.x, &AABB_top.x, d_rays.data(), nullptr));
+}
+
+// gen_rays.cuh:99-159.  EndPointSort without bounds computes them from the points (the
+// reference passes AABB_bot for both corners there, gen_rays.cuh:121-122: not reproduced).
+template <typename PointType>
+inline void one_to_many_rays(device_vector<Ray>& d_rays, const float ox, const float oy,
+                             const float oz, const device_vector<PointType>& d_points,
+                             const enum RaySortType sort_type = DirectionSort)
+{
+    if (sort_type != NoSort && sort_type != DirectionSort && sort_type != EndPointSort)
+        throw std::invalid_argument("Ray sort type not recognized");
+    if (sort_type == EndPointSort) {
+        const std::vector<PointType> h = d_points.to_host();
+        if (h.empty()) throw std::invalid_argument("one_to_many_rays: no points");
+        float3 lo = make_float3(float(h[0].x), float(h[0].y), float(h[0].z)), hi = lo;
+        for (size_t i = 1; i < h.size(); ++i) {
+            const float x = float(h[i].x), y = float(h[i].y), z = float(h[i].z);
+            lo.x = x < lo.x ? x : lo.x; hi.x = x > hi.x ? x : hi.x;
+            lo.y = y < lo.y ? y : lo.y; hi.y = y > hi.y ? y : hi.y;
+            lo.z = z < lo.z ? z : lo.z; hi.z = z > hi.z ? z : hi.z;
+        }
+        one_to_many_rays(d_rays, ox, oy, oz, d_points, lo, hi);
+        return;
+    }
+    if (d_rays.size() < d_points.size()) d_rays.resize(d_points.size());
+    detail::check(grace_rays_one_to_many(d_points.size(), ox, oy, oz, d_points.data(),
+                                         detail::point_traits<PointType>::is_double,
+                                         detail::point_traits<PointType>::elems, int(sort_type),
+                                         nullptr, nullptr, d_rays.data(), nullptr));
+}
+
+// gen_rays.cuh:210-262
+inline void plane_parallel_random_rays(device_vector<Ray>& d_rays, const int width, const int height,
+                                       const float3 base, const float3 w, const float3 h,
+                                       const float length, const unsigned long long seed = 1234)
+{
+    const size_t n = size_t(width) * height;
+    if (d_rays.size() < n) d_rays.resize(n);
+    detail::check(grace_rays_plane_parallel_random(width, height, &base.x, &w.x, &h.x, length, seed,
+                                                   d_rays.data(), nullptr));
+}
+
+// gen_rays.cuh:264-329
+inline void orthographic_projection_rays(device_vector<Ray>& d_rays, const int resolution_x,
+                                         const int resolution_y, const float3 camera_position,
+                                         const float3 look_at, const float3 view_up,
+                                         const float vertical_extent, const float length)
+{
+    const size_t n = size_t(resolution_x) * resolution_y;
+    if (d_rays.size() < n) d_rays.resize(n);
+    detail::check(grace_rays_orthographic_projection(resolution_x, resolution_y, &camera_position.x,
+                                                     &look_at.x, &view_up.x, vertical_extent, length,
+                                                     d_rays.data(), nullptr));
+}
+
+// gen_rays.cuh:331-399
+inline void pinhole_camera_rays(device_vector<Ray>& d_rays, const int resolution_x,
+                                const int resolution_y, const float3 camera_position,
+                                const float3 look_at, const float3 view_up, const float FOVy,
+                                const float length)
+{
+    const size_t n = size_t(resolution_x) * resolution_y;
+    if (d_rays.size() < n) d_rays.resize(n);
+    detail::check(grace_rays_pinhole(resolution_x, resolution_y, &camera_position.x, &look_at.x,
+                                     &view_up.x, FOVy, length, d_rays.data(), nullptr));
+}
+
+// ---- double4 particles (build_sph.cuh:16-82 with Real4 = double4): keys from the co-ordinates
+// narrowed to float (CentroidSphere), 32-byte records moved by the sort.
+inline void morton_keys_sph(const device_vector<double4>& d_spheres, const float3 bot,
+                            const float3 top, device_vector<uinteger32>& d_keys)
+{
+    detail::check(grace_morton_keys30_points(d_spheres.data(), d_spheres.size(), 1, 4, &bot.x, &top.x,
+                                             d_keys.data(), nullptr));
+}
+inline void morton_keys_sph(const device_vector<double4>& d_spheres, const float3 bot,
+                            const float3 top, device_vector<uinteger64>& d_keys)
+{
+    detail::check(grace_morton_keys63_points(d_spheres.data(), d_spheres.size(), 1, 4, &bot.x, &top.x,
+                                             d_keys.data(), nullptr));
+}
+inline void morton_keys30_sort_sph(device_vector<double4>& d_spheres, const float3 bot,
+                                   const float3 top)
+{
+    device_vector<uinteger32> d_keys(d_spheres.size());
+    morton_keys_sph(d_spheres, bot, top, d_keys);
+    detail::check(grace_sort_pairs_u32(d_keys.data(), d_spheres.data(), d_spheres.size(), 32, 0, 30,
+                                       nullptr, nullptr));
+}
+inline void morton_keys63_sort_sph(device_vector<double4>& d_spheres, const float3 bot,
+                                   const float3 top)
+{
+    device_vector<uinteger64> d_keys(d_spheres.size());
+    morton_keys_sph(d_spheres, bot, top, d_keys);
+    detail::check(grace_sort_pairs_u64(d_keys.data(), d_spheres.data(), d_spheres.size(), 32, 0, 63,
+                                       nullptr, nullptr));
 }
 
 // util/extrema.cuh min_vec4 / max_vec4 as used by tests/project_gadget/project_gadget.cu:66-68

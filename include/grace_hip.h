@@ -80,6 +80,18 @@ grace_status grace_morton_keys63_f4_d3(const float* d_spheres, size_t n, const d
                                        const double* h_top, uint64_t* d_keys,
                                        grace_stream stream);
 
+/* morton_keys_sph / morton_keys over other point types (build_sph.cuh:16-33, Real4 = double4;
+ * kernels/gen_rays.cuh:603-604, PointType = float3/float4): n records of elems_per_point
+ * floats (is_double = 0) or doubles (1), x y z first.  Co-ordinates are narrowed to float
+ * before the key arithmetic (CentroidSphere, generic/functors/centroid.h:33-40 --
+ * tests/morton_key_kernel/63bit_keys.cu:52-58).  bot/top: host float[3]. */
+grace_status grace_morton_keys30_points(const void* d_points, size_t n, int is_double,
+                                        int elems_per_point, const float* h_bot,
+                                        const float* h_top, uint32_t* d_keys, grace_stream stream);
+grace_status grace_morton_keys63_points(const void* d_points, size_t n, int is_double,
+                                        int elems_per_point, const float* h_bot,
+                                        const float* h_top, uint64_t* d_keys, grace_stream stream);
+
 /* ---- stable radix sort: the thrust::sort_by_key(keys, values) call sites
  *      (include/grace/cuda/build_sph.cuh:46,57,70,81; kernels/gen_rays.cuh:483,520,577,615).
  *      Keys ascending, equal keys keep their input order; values (value_bytes per element,
@@ -263,6 +275,34 @@ grace_status grace_rays_healpix(int nside, float ox, float oy, float oz, float l
  * (kernels/gen_rays.cuh:38-43,104-170 uniform_random_rays); own counter-based generator. */
 grace_status grace_rays_isotropic(size_t n_rays, float ox, float oy, float oz, float length,
                                   uint64_t seed, void* d_rays, grace_stream stream);
+
+/* uniform_random_rays_single_octant (gen_rays.cuh:62-97; kernels/gen_rays.cuh:161-204,484-517):
+ * octant 0 (MMM) .. 7 (PPP), bit 2 = x, bit 1 = y, bit 0 = z, set = positive component. */
+grace_status grace_rays_isotropic_octant(size_t n_rays, float ox, float oy, float oz, float length,
+                                         int octant, uint64_t seed, void* d_rays,
+                                         grace_stream stream);
+/* one_to_many_rays (gen_rays.cuh:99-208; kernels/gen_rays.cuh:206-243,519-611): ray i goes from
+ * the origin to point i (direction normalised, length = distance).  Points: elems_per_point
+ * floats/doubles each, x y z first.  sort_type: 0 NoSort, 1 DirectionSort (ray_dir_morton_key),
+ * 2 EndPointSort (30-bit Morton key of the end point within h_bot/h_top; the reference's
+ * bounds-free overload passes AABB_bot twice, gen_rays.cuh:121-122 -- not reproduced: pass the
+ * real bounds).  Anything else: GRACE_INVALID_ARGUMENT (std::invalid_argument there). */
+grace_status grace_rays_one_to_many(size_t n_rays, float ox, float oy, float oz,
+                                    const void* d_points, int is_double, int elems_per_point,
+                                    int sort_type, const float* h_bot, const float* h_top,
+                                    void* d_rays, grace_stream stream);
+/* plane_parallel_random_rays (gen_rays.cuh:210-262; kernels/gen_rays.cuh:245-317,613-665): a
+ * width x height grid of cells spanned by w and h from base, one ray per cell from a random
+ * point of the cell, direction normalize(cross(w, h)).  base, w, h: host float[3]. */
+grace_status grace_rays_plane_parallel_random(int width, int height, const float* h_base,
+                                              const float* h_w, const float* h_h, float length,
+                                              uint64_t seed, void* d_rays, grace_stream stream);
+/* orthographic_projection_rays (gen_rays.cuh:264-329; kernels/gen_rays.cuh:319-360,667-725),
+ * Real = float: ray 0 is the top-left pixel, x fastest. */
+grace_status grace_rays_orthographic_projection(int res_x, int res_y, const float* h_camera,
+                                                const float* h_look_at, const float* h_view_up,
+                                                float vertical_extent, float length,
+                                                void* d_rays, grace_stream stream);
 
 #ifdef __cplusplus
 }

@@ -954,3 +954,67 @@ void go_pinhole_rays(int res_x, int res_y, const float* cam, const float* look_a
         rays[tid] = r;
     }
 }
+
+/* orthographic_projection_rays (include/grace/cuda/gen_rays.cuh:264-329;
+ * kernels/gen_rays.cuh:319-360,667-725), Real = float: normalize3 / cross as in
+ * generic/vecmath.h:9-52 (products in float, norm in double), image_plane_coord with aspect
+ * 1 and n = 0 (kernels/gen_rays.cuh:76-95). */
+static void go_cross(const float* u, const float* v, float* out)
+{
+    out[0] = u[1] * v[2] - u[2] * v[1];
+    out[1] = u[2] * v[0] - u[0] * v[2];
+    out[2] = u[0] * v[1] - u[1] * v[0];
+}
+static void go_normalize3(float* v)
+{
+    double N = 1. / sqrt((double)(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));
+    for (int k = 0; k < 3; ++k) v[k] = (float)(v[k] * N);
+}
+void go_orthographic_projection_rays(int res_x, int res_y, const float* cam, const float* look_at,
+                                     const float* up, float vertical_extent, float length,
+                                     go_ray* rays)
+{
+    float aspect = (float)res_x / res_y;
+    float horizontal_extent = vertical_extent * aspect;
+    float vd[3] = { look_at[0] - cam[0], look_at[1] - cam[1], look_at[2] - cam[2] };
+    go_normalize3(vd);
+    float v[3], u[3];
+    go_cross(vd, up, v); go_normalize3(v);
+    go_cross(v, vd, u); go_normalize3(u);
+    for (int k = 0; k < 3; ++k) {
+        v[k] = (float)(v[k] * (horizontal_extent / 2.));
+        u[k] = (float)(u[k] * (vertical_extent / 2.));
+    }
+    for (long tid = 0; tid < (long)res_x * res_y; ++tid) {
+        int i = (int)(tid % res_x), j = (int)(tid / res_x);
+        float x = (2 * ((i + 0.5f) / res_x) - 1) * 1.f;
+        float y = 1 - 2 * ((j + 0.5f) / res_y);
+        float z = 1.f;
+        float p[3];
+        for (int k = 0; k < 3; ++k) p[k] = x * v[k] + y * u[k] + z * 0.f;
+        go_ray r = { vd[0], vd[1], vd[2], cam[0] + p[0], cam[1] + p[1], cam[2] + p[2], length };
+        rays[tid] = r;
+    }
+}
+
+/* one_to_many_rays_kernel (kernels/gen_rays.cuh:206-243), unsorted: points are `stride`
+ * floats (is_double 0) or doubles (1) each.  The reference normalises with rnorm3d on the
+ * device; here 1/sqrt in fp32 (ray inputs are not parity-bound, gen_rays.cuh:21-24). */
+void go_one_to_many_rays(const void* points, int is_double, int stride, size_t n, float ox,
+                         float oy, float oz, go_ray* rays)
+{
+    for (size_t t = 0; t < n; ++t) {
+        float dx, dy, dz;
+        if (is_double) {
+            const double* q = (const double*)points + t * (size_t)stride;
+            dx = (float)(q[0] - ox); dy = (float)(q[1] - oy); dz = (float)(q[2] - oz);
+        } else {
+            const float* q = (const float*)points + t * (size_t)stride;
+            dx = q[0] - ox; dy = q[1] - oy; dz = q[2] - oz;
+        }
+        float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        go_ray r = { dx * inv, dy * inv, dz * inv, ox, oy, oz, (float)(1.0 / (double)inv) };
+        rays[t] = r;
+    }
+}
+

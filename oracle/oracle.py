@@ -329,3 +329,25 @@ def pinhole_rays(res_x, res_y, cam, look_at, up, fovy, length):
     lib().go_pinhole_rays(C.c_int(res_x), C.c_int(res_y), _p(a), _p(b), _p(c), C.c_float(fovy),
                           C.c_float(length), _p(rays))
     return rays
+
+
+def orthographic_projection_rays(res_x, res_y, cam, look_at, up, vertical_extent, length):
+    rays = np.empty(res_x * res_y, RAY_DTYPE)
+    f = lambda v: np.asarray(v, np.float32)
+    a, b, c = f(cam), f(look_at), f(up)
+    lib().go_orthographic_projection_rays(C.c_int(res_x), C.c_int(res_y), _p(a), _p(b), _p(c),
+                                          C.c_float(vertical_extent), C.c_float(length), _p(rays))
+    return rays
+
+
+def one_to_many_rays(origin, points):
+    """Unsorted rays origin -> points[i]; points [n, k>=3] float32 or float64."""
+    points = np.ascontiguousarray(points)
+    assert points.dtype in (np.float32, np.float64) and points.ndim == 2
+    rays = np.empty(len(points), RAY_DTYPE)
+    lib().go_one_to_many_rays(_p(points), C.c_int(int(points.dtype == np.float64)),
+                              C.c_int(points.shape[1]), C.c_size_t(len(points)),
+                              C.c_float(origin[0]), C.c_float(origin[1]), C.c_float(origin[2]),
+                              _p(rays))
+    return rays
+

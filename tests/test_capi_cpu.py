@@ -46,6 +46,14 @@ def test_cpp_header_mirror_is_hip_free(tmp_path):
            "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
     subprocess.check_call(cmd)
     assert exe.exists()
+    # the generator / double4 mirrors too (templates are only checked when instantiated)
+    exe2 = tmp_path / "ray_generators"
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror",
+                           "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "ray_generators.cpp"), "-o", str(exe2),
+                           "-L" + os.path.dirname(LIB), "-lgrace_hip",
+                           "-Wl,-rpath," + os.path.dirname(LIB)])
+    assert exe2.exists()
 
 
 def test_product_path_does_not_touch_the_oracle():

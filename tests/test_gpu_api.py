@@ -81,6 +81,122 @@ def test_isotropic_rays_are_unit_sorted_and_reproducible(gh, oracle, cuda):
     assert np.abs(a[:, :3].mean(axis=0)).max() < 0.05   # isotropy, first moment
 
 
+@pytest.mark.parametrize("octant", [7, 5, 2, 0])
+def test_single_octant_rays(gh, oracle, cuda, octant):
+    """uniform_random_rays_single_octant (gen_rays.cuh:62-97): component signs per enum Octants
+    (bit 2 = x, 1 = y, 0 = z; set = positive), unit length, direction-key order, and the
+    octant-restricted first moment of an isotropic distribution (1/2 per component)."""
+    r = gh.uniform_random_rays_single_octant(8192, (1, 2, 3), 5.0, octant, seed=9, device=cuda).cpu().numpy()
+    sign = np.array([1 if octant & 4 else -1, 1 if octant & 2 else -1, 1 if octant & 1 else -1])
+    assert np.all(r[:, :3] * sign >= 0)
+    assert np.allclose(np.linalg.norm(r[:, :3], axis=1), 1.0, atol=3e-7)
+    assert np.all(r[:, 3:6] == np.array([1, 2, 3], np.float32)) and np.all(r[:, 6] == 5.0)
+    assert np.all(np.diff(oracle.ray_dir_keys(r).astype(np.int64)) >= 0)
+    assert np.abs(r[:, :3].mean(axis=0) * sign - 0.5).max() < 0.02
+    same = gh.uniform_random_rays_single_octant(8192, (1, 2, 3), 5.0, octant, seed=9, device=cuda).cpu().numpy()
+    assert np.array_equal(r, same)
+    with pytest.raises(Exception):
+        gh.uniform_random_rays_single_octant(64, (0, 0, 0), 1.0, 8, device=cuda)
+
+
+@pytest.mark.parametrize("dtype,cols", [(np.float32, 3), (np.float32, 4), (np.float64, 4)])
+def test_one_to_many_rays(gh, oracle, cuda, dtype, cols):
+    """one_to_many_rays (gen_rays.cuh:99-208): unsorted == the oracle's restatement bit for bit;
+    DirectionSort / EndPointSort == a stable sort of the unsorted rays by ray_dir_morton_key /
+    by the end points' 30-bit Morton keys; an unknown sort type is an invalid argument."""
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-2, 3, (5000, cols)).astype(dtype)
+    origin = (0.25, -0.5, 1.0)
+    d = _dev(pts, cuda)
+    ref = oracle.one_to_many_rays(origin, pts)
+    plain = gh.one_to_many_rays(origin, d, gh.NoSort).cpu().numpy()
+    refa = ref.view(np.float32).reshape(-1, 7)
+    assert np.array_equal(plain.view(np.uint32), refa.view(np.uint32))
+    assert np.allclose(plain[:, 3:6] + plain[:, :3] * plain[:, 6:7], pts[:, :3], atol=2e-6)
+    by_dir = gh.one_to_many_rays(origin, d, gh.DirectionSort).cpu().numpy()
+    order = np.argsort(oracle.ray_dir_keys(ref), kind="stable")
+    assert np.array_equal(by_dir, plain[order])
+    bot, top = pts[:, :3].min(0).astype(np.float32), pts[:, :3].max(0).astype(np.float32)
+    by_end = gh.one_to_many_rays(origin, d, gh.EndPointSort, bot, top).cpu().numpy()
+    p4 = np.zeros((len(pts), 4), np.float32); p4[:, :3] = pts[:, :3].astype(np.float32)
+    order = np.argsort(oracle.morton_keys30(p4, bot, top), kind="stable")
+    assert np.array_equal(by_end, plain[order])
+    with pytest.raises(Exception):
+        gh.one_to_many_rays(origin, d, 3)
+
+
+def test_plane_parallel_random_rays(gh, cuda):
+    """plane_parallel_random_rays (gen_rays.cuh:210-262): one ray per cell, origin inside its
+    cell of the (w, h) grid on the base plane, direction normalize(cross(w, h)); the comment's
+    own example (base (5,0,10), w (-5,0,0), h (0,6,0) => direction (0,0,-1))."""
+    W, H = 40, 30
+    base, w, h = (5.0, 0.0, 10.0), (-5.0, 0.0, 0.0), (0.0, 6.0, 0.0)
+    r = gh.plane_parallel_random_rays(W, H, base, w, h, 7.5, seed=3, device=cuda).cpu().numpy()
+    assert r.shape == (W * H, 7)
+    assert np.all(r[:, :3] == np.array([0, 0, -1], np.float32)) and np.all(r[:, 6] == 7.5)
+    i, j = np.arange(W * H) % W, np.arange(W * H) // W
+    fx = (5.0 - r[:, 3]) / (5.0 / W)            # cells along w run from x = 5 downwards
+    fy = r[:, 4] / (6.0 / H)
+    assert np.all((fx >= i - 1e-4) & (fx <= i + 1 + 1e-4))
+    assert np.all((fy >= j - 1e-4) & (fy <= j + 1 + 1e-4)) and np.all(r[:, 5] == 10.0)
+    frac = np.concatenate([fx - i, fy - j])
+    assert abs(frac.mean() - 0.5) < 0.02 and frac.std() > 0.25    # uniform within the cell
+    again = gh.plane_parallel_random_rays(W, H, base, w, h, 7.5, seed=3, device=cuda).cpu().numpy()
+    other = gh.plane_parallel_random_rays(W, H, base, w, h, 7.5, seed=4, device=cuda).cpu().numpy()
+    assert np.array_equal(r, again) and not np.array_equal(r, other)
+    # an oblique plane: every origin satisfies dot(o - base, n) = 0
+    r2 = gh.plane_parallel_random_rays(16, 16, (1, 1, 1), (1, 2, 0), (0, 1, 3), 1.0, device=cuda).cpu().numpy()
+    n = np.cross((1, 2, 0), (0, 1, 3)); n = n / np.linalg.norm(n)
+    assert np.allclose(r2[:, :3], n, atol=1e-6)
+    assert np.abs((r2[:, 3:6] - 1.0) @ n).max() < 1e-5
+
+
+def test_orthographic_projection_rays(gh, oracle, cuda):
+    """orthographic_projection_rays (gen_rays.cuh:264-329) against the oracle's restatement
+    (bit for bit), and against orthogonal_rays_z for the -z view of a unit box."""
+    args = (96, 64, (0.5, -2.0, 0.25), (0.1, 0.4, 0.3), (0.0, 0.2, 1.0), 1.5, 9.0)
+    got = gh.orthographic_projection_rays(*args, device=cuda).cpu().numpy()
+    ref = oracle.orthographic_projection_rays(*args).view(np.float32).reshape(-1, 7)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    d = got[0, :3]
+    assert np.allclose(np.linalg.norm(d), 1.0, atol=1e-6) and np.all(got[:, :3] == d)
+    assert np.abs((got[:, 3:6] - np.array(args[2], np.float32)) @ d).max() < 1e-5   # in the image plane
+    # tests/helper/rays.cuh:55-79 is this generator with a -z camera above the box
+    lo, hi = (0, 0, 0, 0), (1, 1, 1, 0)
+    zr, _ = gh.orthogonal_rays_z(32, lo, hi, device=cuda)
+    pr = gh.orthographic_projection_rays(32, 32, (0.5, 0.5, 1.0), (0.5, 0.5, 0.0), (0, 1, 0), 1.0,
+                                         2.0, device=cuda)
+    assert np.array_equal(zr.cpu().numpy(), pr.cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype,cols,bits", [(np.float64, 4, 63), (np.float64, 4, 30),
+                                             (np.float32, 3, 63), (np.float64, 3, 30)])
+def test_morton_keys_of_double4_and_float3_points(gh, oracle, cuda, dtype, cols, bits):
+    """tests/morton_key_kernel/63bit_keys.cu: keys of double4 points with float3 bounds
+    (-1, 1).  The device narrows each co-ordinate to float first (CentroidSphere returns
+    float3) and then applies scale * (c - min), scale = span / (top - bot) in float
+    (kernels/morton.cuh:38-47,104-113) -- restated by the oracle on the narrowed points.
+    (That test's own host loop multiplies by MAX_KEY without dividing by the box width, so it
+    cannot serve as the oracle.)"""
+    n = 10000
+    rng = np.random.default_rng(63)
+    pts = rng.uniform(-1, 1, (n, cols)).astype(dtype)
+    bot, top = np.float32([-1, -1, -1]), np.float32([1, 1, 1])
+    keys = torch.empty(n, dtype=torch.int64 if bits == 63 else torch.int32, device=cuda)
+    gh.morton_keys_points(_dev(pts, cuda), keys, bot, top)
+    p4 = np.zeros((n, 4), np.float32); p4[:, :3] = pts[:, :3].astype(np.float32)
+    if bits == 63:
+        assert np.array_equal(keys.cpu().numpy().view(np.uint64), oracle.morton_keys63(p4, bot, top))
+    else:
+        assert np.array_equal(keys.cpu().numpy().view(np.uint32), oracle.morton_keys30(p4, bot, top))
+    if dtype == np.float64 and cols == 4 and bits == 63:
+        # morton_keys63_sort_sph<double4> (build_sph.cuh:65-82): sort the 32-byte records by key
+        d = _dev(pts, cuda)
+        gh.sort_by_key(keys, d, 0, 63)
+        order = np.argsort(oracle.morton_keys63(p4, bot, top), kind="stable")
+        assert np.array_equal(d.cpu().numpy(), pts[order])
+
+
 # ---- trace_sph (two-pass per-hit output) ------------------------------------------------------
 @pytest.mark.parametrize("n,n_rays,mpl", [(30000, 512, 32), (5000, 64, 1)])
 def test_trace_sph_hits(gh, oracle, cuda, n, n_rays, mpl):
@@ -384,6 +500,18 @@ def test_generic_functor_trace_program(tmp_path):
                            "-L" + lib, "-lgrace_hip", "-L" + os.path.join(ROOT, "oracle"),
                            "-lgrace_oracle", "-Wl,-rpath," + lib,
                            "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_ray_generators_program(tmp_path):
+    """tests/cpp/ray_generators.cpp: the gen_rays.cuh generators and the double4 key/sort
+    overloads through include/grace/grace.h (plain g++)."""
+    lib = os.path.join(ROOT, "grace-devel_amd", "lib")
+    exe = tmp_path / "ray_generators"
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "ray_generators.cpp"), "-o", str(exe),
+                           "-L" + lib, "-lgrace_hip", "-Wl,-rpath," + lib])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
 
