@@ -70,7 +70,13 @@ def cpu_baseline(spheres_host, rays_host, seconds_target=15.0):
     sample = rays_host[np.linspace(0, n_rays - 1, n_sample).astype(np.int64)]
     t0 = time.perf_counter(); O.brute_cumulative(sample, spheres_host); t1 = time.perf_counter()
     rate = n_sample / (t1 - t0)
+    # BASELINE.md's second host path: the tests/morton_key loop (morton_key(float,float,float),
+    # generic/morton.h:32-42) over the same particles, one thread (the loop is serial there too).
+    nk = min(len(spheres_host), 10_000_000)
+    bot = spheres_host[:nk, :3].min(axis=0); top = spheres_host[:nk, :3].max(axis=0)
+    t2 = time.perf_counter(); O.morton_keys30(spheres_host[:nk], bot, top); t3 = time.perf_counter()
     return {"value": rate / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "morton_key_Mkeys_per_s_1thread": nk / (t3 - t2) / 1e6,
             "sample": "%d of %d rays (evenly spaced over the image) x %d spheres, brute-force "
                       "sphere_hit + kernel-integral accumulation, %.1f s wall"
                       % (n_sample, n_rays, len(spheres_host), t1 - t0),

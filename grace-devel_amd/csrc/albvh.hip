@@ -336,6 +336,12 @@ __global__ __launch_bounds__(256) void nodes_direct_kernel(const MaxPyramid<D> m
     }
 }
 
+// Measurement hook (profile_tree's per-phase lines): HIP events around the leaf stage and the
+// node stage of the last build on its stream.
+bool g_phase_timing = false;
+bool g_phase_valid = false;
+hipEvent_t g_pe[3] = { nullptr, nullptr, nullptr };
+
 template <typename D, int PRIM = PRIM_SPHERE>
 grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, int mpl,
                          int* d_nodes, int* d_leaves, int* d_root, size_t* h_n_leaves,
@@ -363,6 +369,12 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
     uint32_t* d_total = Workspace::take<uint32_t>(1);
     float* boxes = Workspace::take<float>(6 * n);
 
+    if (g_phase_timing) {
+        for (auto& e : g_pe)
+            if (!e) GRACE_TRY_HIP(hipEventCreate(&e));
+        g_phase_valid = false;
+        GRACE_TRY_HIP(hipEventRecord(g_pe[0], stream));
+    }
     const int grid = ceil_div(n, 256);
     leaf_heads_kernel<D><<<grid, 256, 0, stream>>>(d_deltas, ni, mpl, flags, counts);
     GRACE_CHECK_LAUNCH();
@@ -370,6 +382,7 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
     write_leaves_kernel<D><<<grid, 256, 0, stream>>>(flags, counts, pos, d_deltas, ni,
                                                      reinterpret_cast<int4*>(d_leaves), leaf_ds);
     GRACE_CHECK_LAUNCH();
+    if (g_phase_timing) GRACE_TRY_HIP(hipEventRecord(g_pe[1], stream));
     uint32_t n_leaves = 0;
     GRACE_TRY_HIP(hipMemcpyAsync(&n_leaves, d_total, 4, hipMemcpyDeviceToHost, stream));
     GRACE_TRY_HIP(hipStreamSynchronize(stream));
@@ -410,6 +423,10 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
     nodes_direct_kernel<D><<<ceil_div(size_t(n_nodes) + n_leaves, 256), 256, 0, stream>>>(
         mp, bp, leaf_ds, int(n_leaves), d_nodes, d_root);
     GRACE_CHECK_LAUNCH();
+    if (g_phase_timing) {
+        GRACE_TRY_HIP(hipEventRecord(g_pe[2], stream));
+        g_phase_valid = true;
+    }
     return GRACE_OK;
 }
 
@@ -439,6 +456,23 @@ grace_status grace_albvh_build_tri_u32(const float* d_tris, size_t n, const uint
 {
     return albvh_build<uint32_t, PRIM_TRIANGLE>(d_tris, n, d_deltas, max_per_leaf, d_nodes,
                                                 d_leaves, d_root, h_n_leaves, as_stream(stream));
+}
+
+grace_status grace_albvh_enable_timing(int enabled)
+{
+    g_phase_timing = enabled != 0;
+    if (!g_phase_timing) g_phase_valid = false;
+    return GRACE_OK;
+}
+
+grace_status grace_albvh_last_phase_ms(float* h_leaves_ms, float* h_nodes_ms)
+{
+    GRACE_REQUIRE(h_leaves_ms && h_nodes_ms, "albvh_last_phase_ms: null pointer");
+    GRACE_REQUIRE(g_phase_timing && g_phase_valid, "no timed ALBVH build recorded");
+    GRACE_TRY_HIP(hipEventSynchronize(g_pe[2]));
+    GRACE_TRY_HIP(hipEventElapsedTime(h_leaves_ms, g_pe[0], g_pe[1]));
+    GRACE_TRY_HIP(hipEventElapsedTime(h_nodes_ms, g_pe[1], g_pe[2]));
+    return GRACE_OK;
 }
 
 } // extern "C"

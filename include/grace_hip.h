@@ -146,6 +146,14 @@ grace_status grace_morton_keys30_tri(const float* d_tris, size_t n, const float*
 grace_status grace_albvh_build_tri_u32(const float* d_tris, size_t n, const uint32_t* d_deltas,
                                        int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
                                        size_t* h_n_leaves, grace_stream stream);
+
+/* Measurement hook for profile_tree-style harnesses (tests/profile_tree/profile_tree.cu prints
+ * one line per build phase): when enabled, HIP events are recorded on the build's stream around
+ * its leaf stage (leaf heads + scan + leaf records AND their deltas: the reference's
+ * build_leaves, remove_empty_leaves and copy_leaf_deltas, fused here) and its node stage
+ * (leaf boxes, pyramids, nodes: build_nodes). */
+grace_status grace_albvh_enable_timing(int enabled);
+grace_status grace_albvh_last_phase_ms(float* h_leaves_ms, float* h_nodes_ms);
 /* trace_closest_tri (tris_trace.cu:43-62): RayEntry_tri / RayIntersect_tri / OnHit_tri
  * (tris_trace.cuh:11-73) over Moeller-Trumbore with back-face culling (triangle.cuh:54-88);
  * d_closest[ray] = index of the nearest triangle hit, or -1. */

@@ -516,6 +516,52 @@ def test_cpp_ray_generators_program(tmp_path):
     assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
 
 
+def _build_cpp(tmp_path, name):
+    lib = os.path.join(ROOT, "grace-devel_amd", "lib")
+    exe = tmp_path / name
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", str(exe),
+                           "-L" + lib, "-lgrace_hip", "-Wl,-rpath," + lib])
+    return str(exe)
+
+
+def test_cpp_profile_tree_program(tmp_path):
+    """tests/cpp/profile_tree.cpp prints the reference profile_tree's lines (one per build
+    phase), scrapable the way tests/profile_leafbuilders.py scrapes them."""
+    exe = _build_cpp(tmp_path, "profile_tree")
+    r = subprocess.run([exe, "32", "3", "16", "17"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert "Max particles per leaf:   32" in out and "Iterations per tree:      3" in out
+    blocks = out.split("Number of particles:")[1:]
+    assert [int(b.split()[0]) for b in blocks] == [65536, 131072]
+    for b in blocks:
+        times = {}
+        for label in ("Morton key generation", "sort-by-key", "computing deltas", "building leaves",
+                      "computing leaf deltas", "building nodes", "total (inc. memory ops)"):
+            line = [l for l in b.splitlines() if l.startswith("Time for " + label + ":")]
+            assert len(line) == 1 and line[0].rstrip().endswith("ms.")
+            times[label] = float(line[0].split(":")[1].split()[0])
+        assert times["building leaves"] > 0 and times["building nodes"] > 0
+        assert times["total (inc. memory ops)"] >= times["sort-by-key"] > 0
+
+
+def test_cpp_profile_trace_gadget_program(tmp_path):
+    """tests/cpp/profile_trace_gadget.cpp prints the reference profile_trace_gadget's lines."""
+    exe = _build_cpp(tmp_path, "profile_trace_gadget")
+    r = subprocess.run([exe, "64", "32", "synthetic:200000", "2"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert "Number of particles:    200000" in out and "Number of rays:         2048" in out
+    hits = int([l for l in out.splitlines() if l.startswith("Total hits:")][0].split()[2])
+    assert hits > 2048
+    for label in ("generating and sorting rays", "hit count tracing", "cumulative density tracing",
+                  "full tracing", "sort-by-distance", "total (inc. memory ops)"):
+        line = [l for l in out.splitlines() if l.startswith("Time for " + label + ":")]
+        assert len(line) == 1 and float(line[0].split(":")[1].split()[0]) > 0
+
+
 def test_cpp_project_gadget_program(tmp_path):
     """tests/cpp/project_gadget.cpp (mirror of tests/project_gadget): reads a Gadget file
     written by the Python writer, projects it, writes a valid 24-bit BMP."""
