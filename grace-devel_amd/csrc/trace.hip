@@ -520,10 +520,13 @@ __device__ __forceinline__ bool axis_beam_may_hit(const float4 s, const Beam& bm
     return !(b2_lo >= s.w);
 }
 
-template <int MODE, bool SPLIT, bool FAST = false>
+// ALT selects the mode's alternative code path: the fast kernel integral of the column-density
+// trace, the LDS-staged outputs of the per-hit trace.
+template <int MODE, bool SPLIT, bool ALT = false>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
 {
-    static_assert(!FAST || MODE == MODE_CUMULATIVE, "only the column-density trace has a fast integral");
+    static_assert(!ALT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS, "no alternative path for this mode");
+    constexpr bool FAST = ALT && MODE == MODE_CUMULATIVE;
     __shared__ double2 s_lut[FAST ? 1 : N_TABLE];
     __shared__ float2 s_lutf[FAST ? N_TABLE + 1 : 1];
     // Per-wave tile of the candidates of the current culling round (MODE_TRI keeps its
@@ -641,6 +644,36 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     float tri_tmin = len * (1.f + 0.000001f);
     const double ddx = dx, ddy = dy, ddz = dz;
     if (MODE == MODE_HITS) write_at = a.offsets[ray_index];
+    // MODE_HITS: every ray owns a contiguous output segment, so lanes writing hit by hit
+    // touch 64 different cache lines per store and the partial lines thrash L2 (measured:
+    // 48 GB/s of useful output).  Hits are staged per lane in LDS (HIT_CAP entries, entry-major,
+    // padded to 65 columns so that neither the per-lane appends nor the per-ray drains conflict)
+    // and drained by the whole wave: HIT_CAP lanes per ray write HIT_CAP consecutive elements
+    // (2.1 -> 5.0 ms ... 56 -> 20 ms at 0.4 ... 2.1 G hits).  With few packets the walk is
+    // latency-bound and the extra instructions cost more than the stores: the host picks the
+    // staged instantiation from the packet count.
+    constexpr int HIT_CAP = 8;
+    constexpr bool STAGE_HITS = ALT && MODE == MODE_HITS;
+    __shared__ float s_hits[STAGE_HITS ? TRACE_BLOCK / 64 : 1][STAGE_HITS ? 3 : 1]
+                           [STAGE_HITS ? HIT_CAP : 1][STAGE_HITS ? 65 : 1];
+    int staged = 0;            // hits of this lane waiting in LDS; they belong at write_at - staged
+    auto drain_hits = [&]() {
+        const int wvh = threadIdx.x >> 6;
+        constexpr int RAYS_PER_PASS = 64 / HIT_CAP;
+        const int g = lane / HIT_CAP, e = lane % HIT_CAP;
+#pragma unroll 1
+        for (int pass = 0; pass < HIT_CAP; ++pass) {
+            const int src = pass * RAYS_PER_PASS + g;               // the lane whose hits these are
+            const int n_src = __shfl(staged, src);
+            const int first = __shfl(write_at - staged, src);
+            if (e < n_src) {
+                a.hit_idx[first + e] = __float_as_int(s_hits[wvh][0][e][src]);
+                a.hit_integral[first + e] = s_hits[wvh][STAGE_HITS ? 1 : 0][e][src];
+                a.hit_dist[first + e] = s_hits[wvh][STAGE_HITS ? 2 : 0][e][src];
+            }
+        }
+        staged = 0;
+    };
     uint32_t st_nodes = 0, st_leaves = 0, st_tested = 0;
 
     // Packet stack: entry e lives in lane (e & 63) of stk0 (e < 64) or stk1.
@@ -874,13 +907,22 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                                 sum = __builtin_fmaf(w, sb.y, sum);
                             } else if (MODE == MODE_CUMULATIVE) {
                                 sum += w;
-                            } else if (valid) {
+                            } else if (valid && !STAGE_HITS) {
                                 a.hit_idx[write_at] = leaf.x + jj;
                                 a.hit_integral[write_at] = w;
                                 a.hit_dist[write_at] = dot_p;
                                 ++write_at;
+                            } else if (valid) {
+                                const int wvh = threadIdx.x >> 6;
+                                s_hits[wvh][0][staged][lane] = __int_as_float(leaf.x + jj);
+                                s_hits[wvh][STAGE_HITS ? 1 : 0][staged][lane] = w;
+                                s_hits[wvh][STAGE_HITS ? 2 : 0][staged][lane] = dot_p;
+                                ++staged;
+                                ++write_at;
                             }
                         }
+                        if (STAGE_HITS && __builtin_amdgcn_ballot_w64(staged == HIT_CAP) != 0ull)
+                            drain_hits();
                     }
                 };
                 // Fetch a survivor from the wave's LDS tile: slot k of the compacted tile, or the
@@ -950,6 +992,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
         }
     }
 
+    if (STAGE_HITS) drain_hits();
     if ((overflow || junk < 0) && lane == 0) *a.status = GRACE_STACK_OVERFLOW;
     if (!valid) return;
     if (MODE == MODE_COUNT) {
@@ -1113,6 +1156,9 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             if (split > 1) trace_kernel<MODE, true, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
             else trace_kernel<MODE, false, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
         }
+    } else if constexpr (MODE == MODE_HITS) {
+        if (n_packets >= 4096) trace_kernel<MODE, false, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        else trace_kernel<MODE, false, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
     } else if constexpr (MODE == MODE_COUNT) {
         if (split > 1) trace_kernel<MODE, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
         else trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);

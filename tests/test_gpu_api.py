@@ -319,6 +319,33 @@ def test_weighted_segmented_scan(gh, oracle, cuda):
     assert np.array_equal(out.cpu().numpy(), oracle.segscan(offs, w[m] * x))
 
 
+def test_trace_sph_staged_outputs_large_batch(gh, oracle, cuda):
+    """With >= 4096 packets the per-hit trace stages its outputs in LDS and drains them eight
+    entries at a time: same offsets / indices / integrals / distances as the oracle (checked on
+    400 rays of 262 176, a ray count that leaves a half-empty last packet)."""
+    n, n_rays = 30000, 4096 * 64 + 32
+    s = oracle.random_real4(n, (0, 0, 0, 0.002), (1, 1, 1, 0.03))
+    d, tree = _build(gh, cuda, s, 32)
+    rays = gh.uniform_random_rays(n_rays, (0.5, 0.5, 0.5), 2.0, seed=21, device=cuda)
+    offs, idx, integ, dist = gh.trace_sph(rays, d, tree)
+    gh.trace_status()
+    offs = offs.cpu().numpy(); idx = idx.cpu().numpy(); integ = integ.cpu().numpy(); dist = dist.cpu().numpy()
+    hc = torch.empty(n_rays, dtype=torch.int32, device=cuda)
+    gh.trace_hitcounts_sph(rays, d, tree, hc)
+    hc = hc.cpu().numpy()
+    assert np.array_equal(offs, np.concatenate([[0], np.cumsum(hc)[:-1]])) and len(idx) == hc.sum()
+    sub = np.unique(np.concatenate([np.linspace(0, n_rays - 1, 390).astype(np.int64),
+                                    np.arange(n_rays - 10, n_rays)]))
+    ro, ri, rw, rd = oracle.brute_hits(rays.cpu().numpy()[sub], d.cpu().numpy())
+    for k, r in enumerate(sub):
+        a, b = offs[r], offs[r] + hc[r]
+        ra, rb = ro[k], (ro[k + 1] if k + 1 < len(sub) else len(ri))
+        assert b - a == rb - ra
+        assert np.array_equal(idx[a:b], ri[ra:rb])
+        assert np.array_equal(integ[a:b].view(np.uint32), rw[ra:rb].view(np.uint32))
+        assert np.array_equal(dist[a:b].view(np.uint32), rd[ra:rb].view(np.uint32))
+
+
 # ---- KATs on the GPU -------------------------------------------------------------------------
 def test_volume_integral_kat_on_gpu(gh, cuda):
     """tests/integrate/integrate.cu: two spheres (max_per_leaf 1), normalised volume
