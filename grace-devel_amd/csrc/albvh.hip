@@ -45,42 +45,53 @@ __device__ __forceinline__ int opaque(int v)
 }
 
 // ds is the delta array with the reference's +1 shift: ds[k + 1] = delta(k).
-template <typename D>
+//
+// Leaves are the maximal subtrees with at most max_per_leaf primitives, and the node that
+// separates primitives i-1 and i (node i-1) is their lowest common ancestor: they share a
+// leaf iff that node's subtree holds <= max_per_leaf primitives.  Node j's subtree is the
+// maximal run of nodes around j that merge before j does -- to the left while
+// delta(k) < delta(j), to the right while !(delta(j) < delta(k)) (ties merge right first:
+// the "left parent iff delta(l-1) < delta(r)" rule) -- and holds run_left + run_right + 2
+// primitives.  So one thread per primitive decides its head flag with two bounded scans
+// (<= max_per_leaf steps in total, stopping as soon as the count exceeds the bound) over a
+// window of the deltas that the workgroup first copies into LDS; no climbing, no outer loop.
+// (The previous formulation grew every primitive's cluster bottom-up: the same answer, but
+// a wave serialised its lanes' differently-phased scans: 0.76 ms at 8.4 M primitives; this:
+// see profiles/.)
+constexpr int LEAF_TILE_MAX_MPL = 256;
+
+template <typename D, bool TILED>
 __global__ __launch_bounds__(256) void leaf_heads_kernel(const D* __restrict__ ds, int n, int mpl,
-                                                         uint32_t* __restrict__ flags,
-                                                         uint32_t* __restrict__ counts)
+                                                         uint32_t* __restrict__ flags)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int l = i, r = i;
-    for (;;) {
-        if (l == 0 && r == n - 1) break;
-        const D dl = ds[l];     // delta(l - 1)
-        const D dr = ds[r + 1]; // delta(r)
-        if (dl < dr) {
-            // Parent is node l-1; it also owns every primitive to the left whose
-            // separating node is lower in the order: delta(j) < delta(l-1), j < l-1.
-            int nl = l - 1;
-            while (r - nl + 1 <= mpl && nl >= 1 && ds[nl] < dl) --nl;
-            if (opaque(r - nl + 1) > mpl) break;
-            l = nl;
-        } else {
-            // Parent is node r; it owns primitives to the right while the separating
-            // node j > r is lower in the order: !(delta(r) < delta(j)).
-            int nr = r + 1;
-            while (nr - l + 1 <= mpl && nr <= n - 2 && !(dr < ds[nr + 1])) ++nr;
-            if (opaque(nr - l + 1) > mpl) break;
-            r = nr;
-        }
+    __shared__ D tile[TILED ? 256 + 2 * LEAF_TILE_MAX_MPL + 4 : 1];
+    const int b0 = blockIdx.x * blockDim.x;
+    const int lo = b0 - mpl - 1;                   // first delta index held by the tile
+    if (TILED) {
+        const int hi = min(n, b0 + 255 + mpl + 1); // last index (ds has n + 1 entries)
+        for (int k = max(lo, 0) + int(threadIdx.x); k <= hi; k += 256) tile[k - lo] = ds[k];
+        __syncthreads();
     }
-    const bool head = (l == i);
+    auto at = [&](const int k) -> D { return TILED ? tile[k - lo] : ds[k]; };
+    const int i = b0 + threadIdx.x;
+    if (i >= n) return;
+    bool head = true;                              // primitive 0 starts the first leaf
+    if (i > 0) {
+        const int j = i - 1;                       // the node between primitives i-1 and i
+        const D dj = at(j + 1);
+        int size = 2;
+        for (int k = j - 1; size <= mpl && k >= 0 && at(k + 1) < dj; --k) ++size;
+        for (int k = j + 1; size <= mpl && k <= n - 2 && !(dj < at(k + 1)); ++k) ++size;
+        head = opaque(size) > mpl;   // fresh compare: see opaque()
+    }
     flags[i] = head ? 1u : 0u;
-    counts[i] = head ? uint32_t(r - l + 1) : 0u;
 }
 
+// Leaf records and per-leaf deltas (the reference's remove_if + copy_leaf_deltas_kernel,
+// albvh.cuh:51-74,826-846, fused).  A head finds its leaf's size by looking for the next head
+// (<= max_per_leaf steps).
 template <typename D>
 __global__ __launch_bounds__(256) void write_leaves_kernel(const uint32_t* __restrict__ flags,
-                                                           const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ pos,
                                                            const D* __restrict__ ds, int n,
                                                            int4* __restrict__ leaves,
@@ -91,7 +102,8 @@ __global__ __launch_bounds__(256) void write_leaves_kernel(const uint32_t* __res
     if (i == 0) leaf_ds[0] = ds[0];
     if (flags[i]) {
         const int k = int(pos[i]);
-        const int c = int(counts[i]);
+        int c = 1;
+        while (i + c < n && !flags[i + c]) ++c;
         leaves[k] = make_int4(i, c, 0, 0);
         leaf_ds[k + 1] = ds[i + c]; // delta(last primitive of the leaf)
     }
@@ -361,7 +373,8 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
         + Workspace::aligned(n * 24) + 1024;
     GRACE_TRY(Workspace::begin(ws));
     uint32_t* flags = Workspace::take<uint32_t>(n);
-    uint32_t* counts = Workspace::take<uint32_t>(n);
+    uint32_t* counts = Workspace::take<uint32_t>(n); // scratch of the pyramids below
+    (void)counts;
     uint32_t* pos = Workspace::take<uint32_t>(n);
     uint32_t* scan_ws = Workspace::take<uint32_t>(scan_ws_count(n));
     D* leaf_ds = Workspace::take<D>(n + 1);
@@ -376,10 +389,13 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
         GRACE_TRY_HIP(hipEventRecord(g_pe[0], stream));
     }
     const int grid = ceil_div(n, 256);
-    leaf_heads_kernel<D><<<grid, 256, 0, stream>>>(d_deltas, ni, mpl, flags, counts);
+    if (mpl <= LEAF_TILE_MAX_MPL)
+        leaf_heads_kernel<D, true><<<grid, 256, 0, stream>>>(d_deltas, ni, mpl, flags);
+    else
+        leaf_heads_kernel<D, false><<<grid, 256, 0, stream>>>(d_deltas, ni, mpl, flags);
     GRACE_CHECK_LAUNCH();
     GRACE_TRY(exclusive_scan_u32(flags, pos, n, scan_ws, d_total, stream));
-    write_leaves_kernel<D><<<grid, 256, 0, stream>>>(flags, counts, pos, d_deltas, ni,
+    write_leaves_kernel<D><<<grid, 256, 0, stream>>>(flags, pos, d_deltas, ni,
                                                      reinterpret_cast<int4*>(d_leaves), leaf_ds);
     GRACE_CHECK_LAUNCH();
     if (g_phase_timing) GRACE_TRY_HIP(hipEventRecord(g_pe[1], stream));
