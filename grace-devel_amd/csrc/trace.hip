@@ -417,8 +417,34 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
     }
     const int bits = nvar ? min(15, 30 / nvar) : 0;
     const float qmax = float((1 << bits) - 1);
+    // One origin and directions confined to part of the sphere (cameras, cones): scaling each
+    // direction component by its own extent distorts the 3-D curve badly (a camera looking
+    // along z has a tiny, non-linear z extent).  Map the direction to the unit square with the
+    // octahedral parametrisation and order THAT with a 15-bit 2-D curve: a pinhole camera's
+    // pixel grid becomes compact 64-ray patches (closest-hit trace of 10^6 triangles: 13.8 ->
+    // 7.5 ms).  Bundles that cover the whole sphere keep the 3-D curve, which is the better
+    // one there (measured: isotropic and HEALPix sources).
+    const bool pencil = scale[3] == 0.f && scale[4] == 0.f && scale[5] == 0.f && nvar > 0
+        && !(scale[0] > 0.f && scale[0] < 1.f / 1.5f && scale[1] > 0.f && scale[1] < 1.f / 1.5f
+             && scale[2] > 0.f && scale[2] < 1.f / 1.5f);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float* r = rays + 7 * size_t(i);
+        if (pencil) {
+            const float l1 = fabsf(r[0]) + fabsf(r[1]) + fabsf(r[2]);
+            float u = r[0] / l1, v = r[1] / l1;
+            if (r[2] < 0.f) {
+                const float fu = (1.f - fabsf(v)) * (u >= 0.f ? 1.f : -1.f);
+                const float fv = (1.f - fabsf(u)) * (v >= 0.f ? 1.f : -1.f);
+                u = fu; v = fv;
+            }
+            // NaN (zero direction) quantises to 0
+            const uint32_t qu = uint32_t(fminf(32767.f, fmaxf(0.f, (u * 0.5f + 0.5f) * 32767.f + 0.5f)));
+            const uint32_t qv = uint32_t(fminf(32767.f, fmaxf(0.f, (v * 0.5f + 0.5f) * 32767.f + 0.5f)));
+            uint32_t key = 0;
+            for (int b = 14; b >= 0; --b) key = (key << 2) | (((qv >> b) & 1u) << 1) | ((qu >> b) & 1u);
+            keys[i] = key;
+            continue;
+        }
         uint32_t q[6];
 #pragma unroll
         // Round to nearest: a regular ray grid then maps to distinct, evenly spaced cells whatever
@@ -508,6 +534,33 @@ __device__ __forceinline__ bool beam_may_hit(const float4 s, const Beam& bm)
 // q = fl(s - o) in the two perpendicular components.  Rounding is monotone, so replacing each
 // o by the point of the packet's origin interval nearest to s bounds every lane's b2 from
 // below EXACTLY -- no margin, eight instructions.
+// Pencil packet (every ray starts at the same point: point sources, HEALPix / isotropic
+// bundles, pinhole cameras): the rays lie in the cone of half-angle theta around the
+// normalised mean direction a.  A ray at angle <= theta from a passes within h of centre c only
+// if angle(c - o, a) < theta + asin(h / |c - o|) (or the origin is within h of c).  Interval
+// arithmetic on separate origin/direction boxes loses that correlation: on 10^5 isotropic
+// rays through 10^6 spheres it kept 40 k candidates per packet of which 12 k were hit by some
+// ray.  Conservative by an absolute 1e-5 on the cosine and a relative 1e-5 on h^2; explicit
+// FMAs are fine here (a cull, not a result).
+struct Pencil {
+    float ox, oy, oz;     // common origin
+    float ax, ay, az;     // unit axis
+    float sin_t, cos_t;   // half-angle
+};
+
+__device__ __forceinline__ bool pencil_may_hit(const float4 s, const Pencil& pc)
+{
+    const float vx = s.x - pc.ox, vy = s.y - pc.oy, vz = s.z - pc.oz;
+    const float d2 = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, vz * vz));
+    const float va = __builtin_fmaf(vx, pc.ax, __builtin_fmaf(vy, pc.ay, vz * pc.az));
+    const float inv = __builtin_amdgcn_rsqf(d2);
+    const float sin_a = fminf(1.0f, __builtin_amdgcn_sqrtf(s.w) * inv * 1.00001f);
+    const float cos_a = __builtin_amdgcn_sqrtf(fmaxf(0.0f, __builtin_fmaf(-sin_a, sin_a, 1.0f)));
+    const float cos_limit = __builtin_fmaf(pc.cos_t, cos_a, -pc.sin_t * sin_a) - 1e-5f;
+    // !(a < b) forms keep the sphere on any NaN (d2 = 0: the origin is the centre).
+    return !(d2 > s.w * 1.00001f) || !(va * inv < cos_limit);
+}
+
 template <int AX>
 __device__ __forceinline__ bool axis_beam_may_hit(const float4 s, const Beam& bm)
 {
@@ -605,6 +658,31 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     // (s_a - o_a) * d_a with d_a = +-1 is the correctly rounded +-(s_a - o_a): one FMA
     // s_a * d_a + (-o_a * d_a) gives the same bits (both products are exact).
     const float noda = -(oa * da);
+    // Pencil packets: one origin, directions inside a cone narrower than 60 degrees.
+    Pencil pencil;
+    bool is_pencil = false;
+    if (axis < 0 && MODE != MODE_STATS && beam.olo[0] == beam.ohi[0] && beam.olo[1] == beam.ohi[1]
+        && beam.olo[2] == beam.ohi[2]) {
+        float sx = dx, sy = dy, sz = dz;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
+        }
+        const float inv = 1.0f / sqrtf(sx * sx + sy * sy + sz * sz);
+        const float ax = sx * inv, ay = sy * inv, az = sz * inv;
+        // |a x d| = sin(angle): accurate for the small angles that matter; + margin for the
+        // rounding of a and of the (unit) directions.
+        const float cx = ay * dz - az * dy, cy = az * dx - ax * dz, cz = ax * dy - ay * dx;
+        const float sin_t = wave_max(sqrtf(cx * cx + cy * cy + cz * cz)) + 2e-6f;
+        const float cos_min = wave_min(ax * dx + ay * dy + az * dz);
+        if (cos_min > 0.5f && sin_t < 0.8660254f) {   // also false for NaN (zero mean direction)
+            is_pencil = true;
+            pencil.ox = beam.olo[0]; pencil.oy = beam.olo[1]; pencil.oz = beam.olo[2];
+            pencil.ax = ax; pencil.ay = ay; pencil.az = az;
+            pencil.sin_t = sin_t;
+            pencil.cos_t = sqrtf(1.0f - sin_t * sin_t);
+        }
+    }
     // For the range-check-free sweep (below): the packet's extremes of -o_a d_a and of the ray
     // length, and whether all rays point the same way along the axis.
     float noda_lo = 0.f, noda_hi = 0.f, len_lo = 0.f, da0 = 0.f;
@@ -804,6 +882,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                 }
                 bool keep;
                 if constexpr (AX >= 0) keep = lane < m && axis_beam_may_hit<AX>(mine, beam);
+                else if constexpr (AX == -2) keep = lane < m && pencil_may_hit(mine, pencil);
                 else keep = lane < m && beam_may_hit(mine, beam);
                 // Axis packets: if every kept candidate lies inside every ray's [0, length)
                 // along the axis -- decided per candidate with the same FMA the rays use, which
@@ -985,7 +1064,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             case 0: sweep_range(std::integral_constant<int, 0>()); break;
             case 1: sweep_range(std::integral_constant<int, 1>()); break;
             case 2: sweep_range(std::integral_constant<int, 2>()); break;
-            default: sweep_range(std::integral_constant<int, -1>()); break;
+            default:
+                if (is_pencil) sweep_range(std::integral_constant<int, -2>());
+                else sweep_range(std::integral_constant<int, -1>());
+                break;
             }
             // Keep the warming load alive (child / primitive indices are never negative).
             junk |= warm;
