@@ -101,13 +101,31 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # One GPU per rank.  GRACE_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs
+    # than ranks (ranks then share devices and collectives go through host memory).
+    backend = os.environ.get("GRACE_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def all_reduce(t, op=None):
+        """In place; host staging under the gloo rehearsal backend."""
+        kw = {} if op is None else {"op": op}
+        if backend == "nccl":
+            dist.all_reduce(t, **kw)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
 
     import grace_hip as gh  # raises if libgrace_hip.so is missing: no fallback
 
@@ -163,7 +181,7 @@ def main():
     # ---- algorithmic bytes, counted per ray by the instrumented walk ------
     stats = gh.trace_stats(my_rays, spheres, tree).to(torch.int64).sum(dim=0)
     if world > 1:
-        dist.all_reduce(stats)
+        all_reduce(stats)
     nodes_v, leaves_v, tested, hits = [int(x) for x in stats.tolist()]
     alg_bytes_total = 28 * n_rays + 64 * nodes_v + 16 * leaves_v + 16 * tested + 4 * n_rays
     gh.trace_status()
@@ -200,7 +218,7 @@ def main():
     gh.enable_kernel_timing(False)
     t = torch.tensor([elapsed, kern_ms, call_ms], dtype=torch.float64, device=device)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms, call_ms = float(t[0]), float(t[1]), float(t[2])
     gh.trace_status()
 

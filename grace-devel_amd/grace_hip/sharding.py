@@ -24,6 +24,11 @@ def gather_results(my_out, n_rays, world, dist=None):
     ray order on every rank."""
     if world == 1:
         return my_out[:n_rays]
+    if my_out.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal without RCCL (several ranks sharing one GPU): gloo gathers host tensors
+        host = torch.empty(my_out.numel() * world, dtype=my_out.dtype)
+        dist.all_gather_into_tensor(host, my_out.cpu())
+        return host.to(my_out.device)[:n_rays]
     full = torch.empty(my_out.numel() * world, dtype=my_out.dtype, device=my_out.device)
     dist.all_gather_into_tensor(full, my_out)
     return full[:n_rays]
