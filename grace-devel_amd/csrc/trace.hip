@@ -130,6 +130,8 @@ struct TraceArgs {
     int split;              // waves per packet (1, 2, 4, 8); each owns SUM_CLASSES / split classes
     int n_prims;
     float* partial;         // split > 1, cumulative: [n_rays][split] subtree sums
+    int width;              // rays per packet: 64, or 32 / 16 for small batches of the modes that
+                            // cannot split a packet (lanes >= width re-trace the packet's last ray)
     const float4* nodes;    // 4 x float4 per node
     int n_nodes;
     const int4* leaves;
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     static_assert(!SPLIT || SPLITTABLE, "only hit counts and column densities split");
     const int split = SPLIT ? a.split : 1;
     const int packet = wave_id / split, part = wave_id - packet * split;
-    const int first_ray = packet * 64;
+    const int first_ray = packet * a.width;
     if (first_ray >= a.n_rays) return;
     // Summation classes owned by this wave: [own_lo, own_hi).
     const int classes_per_part = SUM_CLASSES / split;
@@ -624,9 +626,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
         return g1 - g0 <= 1 && !owns_granule(g0) && !owns_granule(g1);
     };
     const int slot_index = first_ray + lane;
-    const bool valid = slot_index < a.n_rays;
-    // Tail lanes re-trace the last ray so that they do not widen the packet.
-    const int slot_clamped = valid ? slot_index : a.n_rays - 1;
+    const bool valid = lane < a.width && slot_index < a.n_rays;
+    // Idle and tail lanes re-trace the packet's last ray so that they do not widen the packet.
+    const int slot_clamped = valid ? slot_index : min(first_ray + a.width, a.n_rays) - 1;
     const int ray_index = a.perm ? int(a.perm[slot_clamped]) : slot_clamped;
     const float* rp = a.rays + 7 * size_t(ray_index);
     const float dx = rp[0], dy = rp[1], dz = rp[2];
@@ -1142,6 +1144,7 @@ __global__ __launch_bounds__(256) void combine_classes_kernel(const float* __res
 }
 
 int g_split = -1; // waves per packet; -1: automatic
+int g_width = -1; // rays per packet of the per-hit / triangle traces; -1: automatic
 bool g_exact_integrals = false; // column-density trace: bit-reproducible per-hit arithmetic
 
 template <int MODE>
@@ -1211,7 +1214,16 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     a.n_rays = int(n_rays);
     a.n_nodes = int(n_nodes);
     a.status = g_status;
-    const int n_packets = ceil_div(n_rays, 64);
+    // Per-hit and triangle traces cannot split a packet among waves (their outputs are ordered
+    // / reduced per ray inside one wave); with few rays they use narrower packets instead:
+    // 2-4x the waves, each with a tighter beam, on a chip that would otherwise sit idle.
+    int width = 64;
+    if (MODE == MODE_HITS || MODE == MODE_TRI) {
+        if (g_width > 0) width = g_width;
+        else while (width > 16 && ceil_div(n_rays, size_t(width)) < 4096) width /= 2;
+    }
+    a.width = width;
+    const int n_packets = ceil_div(n_rays, size_t(width));
     // Waves per packet: two resident sets of waves (2 x 8192) for small ray batches.
     int split = 1;
     if (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) {
@@ -1382,6 +1394,15 @@ grace_status grace_trace_set_packet_split(int waves_per_packet)
                       || waves_per_packet == 4 || waves_per_packet == 8,
                   "packet split must be 1, 2, 4, 8 or -1 (automatic)");
     g_split = waves_per_packet;
+    return GRACE_OK;
+}
+
+grace_status grace_trace_set_packet_width(int rays_per_packet)
+{
+    GRACE_REQUIRE(rays_per_packet == -1 || rays_per_packet == 16 || rays_per_packet == 32
+                      || rays_per_packet == 64,
+                  "packet width must be 16, 32, 64 or -1 (automatic)");
+    g_width = rays_per_packet;
     return GRACE_OK;
 }
 

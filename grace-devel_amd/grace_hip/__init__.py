@@ -265,6 +265,10 @@ def set_packet_split(k):
     _check(_lib.grace_trace_set_packet_split(C.c_int(int(k))))
 
 
+def set_packet_width(w):
+    _check(_lib.grace_trace_set_packet_width(C.c_int(int(w))))
+
+
 def set_exact_integrals(enabled):
     """Column-density trace: True = the reference's per-hit arithmetic bit for bit (slower);
     False (default) = hardware sqrt + fp32 table lerp (within the stated 1e-5 tolerance)."""

@@ -215,6 +215,11 @@ grace_status grace_trace_last_kernel_ms(float* h_ms);
  * depend on it (see csrc/trace.hip, "class-ordered sums and packet splitting"). */
 grace_status grace_trace_set_packet_split(int waves_per_packet);
 
+/* Rays per packet of the per-hit and triangle traces (which cannot split a packet among waves):
+ * 64, 32 or 16, or -1 (default) = halve while the call has fewer than 4096 packets.  Results do
+ * not depend on it. */
+grace_status grace_trace_set_packet_width(int rays_per_packet);
+
 /* Column-density trace (grace_trace_cumulative_f4) only.  0 (default): each hit's kernel
  * integral is evaluated with the hardware sqrt (1 ulp) and an fp32 table lerp -- within a few
  * ulp of the reference arithmetic per term, column densities within 1e-6 of the fp64 sum
