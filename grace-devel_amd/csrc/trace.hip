@@ -548,6 +548,10 @@ struct Pencil {
     float ox, oy, oz;     // common origin
     float ax, ay, az;     // unit axis
     float sin_t, cos_t;   // half-angle
+    // Four planes through the origin bounding the bundle in the tangent frame (u, v) of the
+    // axis: outward unit normals.  A sphere wholly outside any of them (n . (c - o) > h) cannot
+    // be hit.  Tightens the cone where the bundle's footprint is not round.
+    float nx[4], ny[4], nz[4];
 };
 
 __device__ __forceinline__ bool pencil_may_hit(const float4 s, const Pencil& pc)
@@ -559,8 +563,13 @@ __device__ __forceinline__ bool pencil_may_hit(const float4 s, const Pencil& pc)
     const float sin_a = fminf(1.0f, __builtin_amdgcn_sqrtf(s.w) * inv * 1.00001f);
     const float cos_a = __builtin_amdgcn_sqrtf(fmaxf(0.0f, __builtin_fmaf(-sin_a, sin_a, 1.0f)));
     const float cos_limit = __builtin_fmaf(pc.cos_t, cos_a, -pc.sin_t * sin_a) - 1e-5f;
+    const float h = __builtin_amdgcn_sqrtf(s.w) * 1.00001f + 1e-6f * __builtin_amdgcn_sqrtf(d2);
+    float out = -1.0f;   // largest signed distance beyond a side plane, in units of length
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        out = fmaxf(out, __builtin_fmaf(vx, pc.nx[k], __builtin_fmaf(vy, pc.ny[k], vz * pc.nz[k])) - h);
     // !(a < b) forms keep the sphere on any NaN (d2 = 0: the origin is the centre).
-    return !(d2 > s.w * 1.00001f) || !(va * inv < cos_limit);
+    return !(d2 > s.w * 1.00001f) || (!(va * inv < cos_limit) && !(out > 0.0f));
 }
 
 template <int AX>
@@ -683,6 +692,31 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             pencil.ax = ax; pencil.ay = ay; pencil.az = az;
             pencil.sin_t = sin_t;
             pencil.cos_t = sqrtf(1.0f - sin_t * sin_t);
+            // tangent frame: u perpendicular to a (built from the axis' smallest component), v = a x u
+            float ux, uy, uz;
+            if (fabsf(ax) <= fabsf(ay) && fabsf(ax) <= fabsf(az)) { ux = 0.f; uy = -az; uz = ay; }
+            else if (fabsf(ay) <= fabsf(az)) { ux = az; uy = 0.f; uz = -ax; }
+            else { ux = -ay; uy = ax; uz = 0.f; }
+            const float un = 1.0f / sqrtf(ux * ux + uy * uy + uz * uz);
+            ux *= un; uy *= un; uz *= un;
+            const float vx = ay * uz - az * uy, vy = az * ux - ax * uz, vz = ax * uy - ay * ux;
+            // gnomonic co-ordinates of every direction (d . a > 0.5 here), their extremes
+            const float da_ = ax * dx + ay * dy + az * dz;
+            const float tu = (ux * dx + uy * dy + uz * dz) / da_, tv = (vx * dx + vy * dy + vz * dz) / da_;
+            const float m = 4e-6f;   // rounding of the frame and of the directions
+            const float tu_lo = wave_min(tu) - m, tu_hi = wave_max(tu) + m;
+            const float tv_lo = wave_min(tv) - m, tv_hi = wave_max(tv) + m;
+            // side plane "t_u <= tu_hi": points p with p.u - tu_hi p.a <= 0; outward normal u - tu_hi a
+            auto plane = [&](int k, float cu, float cv, float ca) {
+                float px = cu * ux + cv * vx + ca * ax, py = cu * uy + cv * vy + ca * ay,
+                      pz = cu * uz + cv * vz + ca * az;
+                const float pn = 1.0f / sqrtf(px * px + py * py + pz * pz);
+                pencil.nx[k] = px * pn; pencil.ny[k] = py * pn; pencil.nz[k] = pz * pn;
+            };
+            plane(0, 1.f, 0.f, -tu_hi);
+            plane(1, -1.f, 0.f, tu_lo);
+            plane(2, 0.f, 1.f, -tv_hi);
+            plane(3, 0.f, -1.f, tv_lo);
         }
     }
     // For the range-check-free sweep (below): the packet's extremes of -o_a d_a and of the ray
