@@ -670,6 +670,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     // s_a * d_a + (-o_a * d_a) gives the same bits (both products are exact).
     const float noda = -(oa * da);
     // Pencil packets: one origin, directions inside a cone narrower than 60 degrees.
+    // The 20 constants live in LDS (one record per wave) and are re-read by every culling round
+    // of a pencil sweep: held in registers they would be live across the whole walk and cost
+    // every instantiation 16 VGPRs -- two waves of occupancy for the orthographic kernels that
+    // never use them.
+    __shared__ Pencil s_pencil[TRACE_BLOCK / 64];
     Pencil pencil;
     bool is_pencil = false;
     if (axis < 0 && MODE != MODE_STATS && beam.olo[0] == beam.ohi[0] && beam.olo[1] == beam.ohi[1]
@@ -717,6 +722,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             plane(1, -1.f, 0.f, tu_lo);
             plane(2, 0.f, 1.f, -tv_hi);
             plane(3, 0.f, -1.f, tv_lo);
+            if (lane == 0) s_pencil[threadIdx.x >> 6] = pencil;
         }
     }
     // For the range-check-free sweep (below): the packet's extremes of -o_a d_a and of the ray
@@ -918,7 +924,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                 }
                 bool keep;
                 if constexpr (AX >= 0) keep = lane < m && axis_beam_may_hit<AX>(mine, beam);
-                else if constexpr (AX == -2) keep = lane < m && pencil_may_hit(mine, pencil);
+                else if constexpr (AX == -2) keep = lane < m && pencil_may_hit(mine, s_pencil[threadIdx.x >> 6]);
                 else keep = lane < m && beam_may_hit(mine, beam);
                 // Axis packets: if every kept candidate lies inside every ray's [0, length)
                 // along the axis -- decided per candidate with the same FMA the rays use, which
@@ -1252,10 +1258,9 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     // / reduced per ray inside one wave); with few rays they use narrower packets instead:
     // 2-4x the waves, each with a tighter beam, on a chip that would otherwise sit idle.
     int width = 64;
-    if (MODE == MODE_HITS || MODE == MODE_TRI) {
-        if (g_width > 0) width = g_width;
-        else while (width > 16 && ceil_div(n_rays, size_t(width)) < 4096) width /= 2;
-    }
+    if (g_width > 0) width = g_width;
+    else if (MODE == MODE_HITS || MODE == MODE_TRI)
+        while (width > 16 && ceil_div(n_rays, size_t(width)) < 4096) width /= 2;
     a.width = width;
     const int n_packets = ceil_div(n_rays, size_t(width));
     // Waves per packet: two resident sets of waves (2 x 8192) for small ray batches.
