@@ -197,6 +197,28 @@ def test_morton_keys_of_double4_and_float3_points(gh, oracle, cuda, dtype, cols,
         assert np.array_equal(d.cpu().numpy(), pts[order])
 
 
+def test_isotropic_ray_statistics(gh, cuda):
+    """tests/isotropic_ray_stats/uniformity_stats.cu: Rayleigh's z = 3 R^2 / n <= 7.815 and Gine's
+    F_n = A_n + G_n <= 1.9478, A_n = n - 4/(n pi) SUM psi_ij (Beran), G_n = n/2 - 4/(n pi) SUM
+    sin psi_ij over all pairs, for the default-seed isotropic generator (4096 rays)."""
+    n = 4096
+    r = gh.uniform_random_rays(n, (0.0, 0.0, 0.0), 1.0, seed=1234, device=cuda)[:, :3].double()
+    R2 = float((r.sum(dim=0) ** 2).sum())
+    z = 3.0 * R2 / n
+    cosm = (r @ r.T).clamp(-1.0, 1.0)
+    iu = torch.triu_indices(n, n, offset=1, device=cuda)
+    c = cosm[iu[0], iu[1]]
+    # angular separation with the numerically safe form 2 asin(|a - b| / 2)
+    diff = (r[iu[0]] - r[iu[1]]).norm(dim=1)
+    psi = 2.0 * torch.asin((diff / 2.0).clamp(max=1.0))
+    coeff = 4.0 / (n * np.pi)
+    An = n - coeff * float(psi.sum())
+    Gn = n / 2.0 - coeff * float(torch.sin(psi).sum())
+    assert c.numel() == n * (n - 1) // 2
+    assert z <= 7.815, z
+    assert An + Gn <= 1.9478, (An, Gn)
+
+
 # ---- trace_sph (two-pass per-hit output) ------------------------------------------------------
 @pytest.mark.parametrize("n,n_rays,mpl", [(30000, 512, 32), (5000, 64, 1)])
 def test_trace_sph_hits(gh, oracle, cuda, n, n_rays, mpl):
@@ -344,6 +366,56 @@ def test_trace_sph_staged_outputs_large_batch(gh, oracle, cuda):
         assert np.array_equal(idx[a:b], ri[ra:rb])
         assert np.array_equal(integ[a:b].view(np.uint32), rw[ra:rb].view(np.uint32))
         assert np.array_equal(dist[a:b].view(np.uint32), rd[ra:rb].view(np.uint32))
+
+
+def test_sphere_intersection_against_exact_arithmetic(gh, oracle, cuda):
+    """tests/sphere_intersection/sphere_intersection.cu: every (ray, sphere) hit decision against
+    an exact reference -- does a*t^2 + b*t + c = 0 have a root in [0, length], in rational
+    arithmetic on the inputs as given (the direction is NOT assumed to be of unit length)?
+    Disagreement is allowed only where |1 - b_ref^2 / R^2| <= 1e-8 (the reference's
+    tolerance).  Same geometry: centres U[-1e4, 1e4)^3, radii U[80, 400), pushed 400 away from
+    the rays' common origin so that no sphere contains it.  float64 screens the 5e7 pairs;
+    every mismatch is then decided with fractions.Fraction."""
+    from fractions import Fraction
+    n, n_rays = 50000, 1024
+    s = oracle.random_real4(n, (-1e4, -1e4, -1e4, 80.0), (1e4, 1e4, 1e4, 400.0))
+    s[:, :3] += np.float32(400.0) * np.sign(s[:, :3])            # expand_functor, :22-36
+    d, tree = _build(gh, cuda, s, 32, (-1.1e4,) * 3, (1.1e4,) * 3)
+    rays = gh.uniform_random_rays(n_rays, (0.0, 0.0, 0.0), 2e4, seed=1234, device=cuda)
+    offs, idx, _, _ = gh.trace_sph(rays, d, tree)
+    gh.trace_status()
+    offs = offs.cpu().numpy(); idx = idx.cpu().numpy()
+    ss = d.cpu().numpy().astype(np.float64); rr = rays.cpu().numpy().astype(np.float64)
+    hit_gpu = np.zeros((n_rays, n), bool)
+    ends = np.concatenate([offs[1:], [len(idx)]])
+    for r in range(n_rays):
+        hit_gpu[r, idx[offs[r]:ends[r]]] = True
+    R2 = ss[:, 3] ** 2
+    n_checked = 0
+    for r0 in range(0, n_rays, 64):                               # float64 screen, 64 rays at a time
+        dd = rr[r0:r0 + 64, None, :3]; oo = rr[r0:r0 + 64, None, 3:6]; L = rr[r0:r0 + 64, None, 6]
+        p = oo - ss[None, :, :3]
+        a = (dd * dd).sum(-1); b = 2 * (dd * p).sum(-1); c = (p * p).sum(-1) - R2[None, :]
+        disc = b * b - 4 * a * c
+        tv = -b / (2 * a)
+        fL = a * L * L + b * L + c
+        ref = (disc >= 0) & ((c * fL <= 0) | ((tv >= 0) & (tv <= L) & (c >= 0) & (fL >= 0)))
+        for rl, si in zip(*np.nonzero(ref != hit_gpu[r0:r0 + 64])):
+            ray = [Fraction(float(x)) for x in rays.cpu().numpy()[r0 + rl]]
+            sph = [Fraction(float(x)) for x in d.cpu().numpy()[si]]
+            dx, dy, dz, ox, oy, oz, Lx = ray
+            px, py, pz = ox - sph[0], oy - sph[1], oz - sph[2]
+            A = dx * dx + dy * dy + dz * dz
+            B = 2 * (dx * px + dy * py + dz * pz)
+            Cc = px * px + py * py + pz * pz - sph[3] * sph[3]
+            D = B * B - 4 * A * Cc
+            f0, fl, tvx = Cc, A * Lx * Lx + B * Lx + Cc, -B / (2 * A)
+            exact = D >= 0 and (f0 * fl <= 0 or (0 <= tvx <= Lx and f0 >= 0 and fl >= 0))
+            b2 = (px * px + py * py + pz * pz) - (B / 2) ** 2 / A      # exact squared impact parameter
+            n_checked += 1
+            assert exact == bool(hit_gpu[r0 + rl, si]) or abs(1 - float(b2 / (sph[3] * sph[3]))) <= 1e-8, \
+                (r0 + rl, si, exact, float(b2), float(sph[3] ** 2))
+    assert hit_gpu.sum() > 10000 and n_checked < 200        # only boundary cases may need the exact path
 
 
 # ---- KATs on the GPU -------------------------------------------------------------------------
