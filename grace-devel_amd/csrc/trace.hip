@@ -93,6 +93,7 @@ namespace {
 
 constexpr int TRACE_BLOCK = 256;
 constexpr int N_TABLE = 51;
+constexpr int MAX_HIT_CHUNKS = 256; // chunk ranges of the split per-hit trace
 constexpr int SUM_CLASSES = 8;   // summation classes (leaves of the pairwise sum tree)
 constexpr int GRANULE_SHIFT = 10; // 1024 consecutive primitives share a class
 
@@ -130,6 +131,14 @@ struct TraceArgs {
     int split;              // waves per packet (1, 2, 4, 8); each owns SUM_CLASSES / split classes
     int n_prims;
     float* partial;         // split > 1, cumulative: [n_rays][split] subtree sums
+    // Split per-hit trace (small batches): primitives are cut into n_chunks ranges of
+    // 2^chunk_shift consecutive indices.  The counting pass fills chunk_counts[ray][chunk];
+    // the per-hit pass lets wave (packet, part) own chunks part_bounds[packet][part ..
+    // part + 1) and writes a ray's hits of a chunk from chunk_off[ray][chunk] on.
+    int* chunk_counts;
+    const int* chunk_off;
+    const int* part_bounds;
+    int chunk_shift, n_chunks;
     int width;              // rays per packet: 64, or 32 / 16 for small batches of the modes that
                             // cannot split a packet (lanes >= width re-trace the packet's last ray)
     const float4* nodes;    // 4 x float4 per node
@@ -618,8 +627,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     const int vblock = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
     const int wave_id = __builtin_amdgcn_readfirstlane(vblock * (TRACE_BLOCK / 64)
                                                        + (threadIdx.x >> 6));
-    constexpr bool SPLITTABLE = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE);
-    static_assert(!SPLIT || SPLITTABLE, "only hit counts and column densities split");
+    constexpr bool SPLITTABLE = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
+    static_assert(!SPLIT || SPLITTABLE, "triangle and stats walks do not split");
+    // Hit counts and column densities split a packet by summation class (interleaved granules);
+    // the per-hit trace, whose output is ordered, by contiguous chunk ranges chosen per packet.
+    constexpr bool RANGE_SPLIT = SPLIT && MODE == MODE_HITS;
     const int split = SPLIT ? a.split : 1;
     const int packet = wave_id / split, part = wave_id - packet * split;
     const int first_ray = packet * a.width;
@@ -627,10 +639,22 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     // Summation classes owned by this wave: [own_lo, own_hi).
     const int classes_per_part = SUM_CLASSES / split;
     const int own_lo = part * classes_per_part, own_hi = own_lo + classes_per_part;
-    auto owns_granule = [&](const int g) { const int c = g & (SUM_CLASSES - 1); return c >= own_lo && c < own_hi; };
-    // True if no primitive of [first, first + count) belongs to this wave (ranges of up to
-    // two granules are decided exactly; longer ones are descended / swept).
+    // Primitive range owned by this wave (RANGE_SPLIT).
+    int prim_lo = 0, prim_hi = 0x7fffffff;
+    if (RANGE_SPLIT) {
+        prim_lo = a.part_bounds[packet * (split + 1) + part] << a.chunk_shift;
+        prim_hi = a.part_bounds[packet * (split + 1) + part + 1] << a.chunk_shift;
+        if (prim_lo >= prim_hi) return;
+    }
+    auto owns_granule = [&](const int g) {
+        if (RANGE_SPLIT) { const int p = g << GRANULE_SHIFT; return p >= prim_lo && p < prim_hi; }
+        const int c = g & (SUM_CLASSES - 1);
+        return c >= own_lo && c < own_hi;
+    };
+    // True if no primitive of [first, first + count) belongs to this wave (class split: ranges
+    // of up to two granules are decided exactly; longer ones are descended / swept).
     auto foreign_range = [&](const int first, const int count) {
+        if (RANGE_SPLIT) return first + count <= prim_lo || first >= prim_hi;
         const int g0 = first >> GRANULE_SHIFT, g1 = (first + count - 1) >> GRANULE_SHIFT;
         return g1 - g0 <= 1 && !owns_granule(g0) && !owns_granule(g1);
     };
@@ -739,6 +763,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     const float o2 = axis == 2 ? oy : oz;
 
     int count = 0;
+    // Chunk bookkeeping of the split per-hit trace (see TraceArgs): the counting pass adds each
+    // lane's hits of a chunk to chunk_counts when the walk leaves the chunk; the per-hit pass
+    // repositions each lane's output cursor when it enters one.
+    constexpr bool CHUNKED = (SPLIT && (MODE == MODE_COUNT || MODE == MODE_HITS));
+    int cur_chunk = -1;        // wave-uniform
+    int count_at_chunk = 0;
     float sum = 0.f;        // accumulator of the current granule's class (MODE_CUMULATIVE)
     // Class accumulators of this wave's lanes (one wave = one row of the workgroup's array).
     constexpr bool CLASSES = (MODE == MODE_CUMULATIVE);
@@ -759,6 +789,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
         sum = s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane];
     };
     int write_at = 0;
+    auto leave_chunk = [&]() {
+        if (MODE == MODE_COUNT && cur_chunk >= 0 && valid && count != count_at_chunk)
+            atomicAdd(&a.chunk_counts[size_t(ray_index) * a.n_chunks + cur_chunk],
+                      count - count_at_chunk);
+        count_at_chunk = count;
+    };
+    auto enter_chunk = [&](const int chunk) {
+        leave_chunk();
+        cur_chunk = chunk;
+        if (MODE == MODE_HITS) write_at = a.chunk_off[size_t(ray_index) * a.n_chunks + chunk];
+    };
     // MODE_TRI: RayEntry_tri (tris_trace.cuh:63-73): closest index -1, t_min = length (1 + eps)
     int tri_data = -1;
     float tri_tmin = len * (1.f + 0.000001f);
@@ -982,6 +1023,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         next_slot += __builtin_popcountll(todo);
                         continue;
                     }
+                    if (CHUNKED && (MODE == MODE_HITS || a.chunk_counts) && (pf >> a.chunk_shift) != cur_chunk)
+                        enter_chunk(pf >> a.chunk_shift);
                 }
                 // One survivor: the packet's 64 rays against candidate jj (wave-uniform).
                 auto process = [&](auto lean_tag, const float4 s, const float2 sb, const int jj) {
@@ -1117,6 +1160,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     }
 
     if (STAGE_HITS) drain_hits();
+    if (CHUNKED && MODE == MODE_COUNT && a.chunk_counts) leave_chunk();
     if ((overflow || junk < 0) && lane == 0) *a.status = GRACE_STACK_OVERFLOW;
     if (!valid) return;
     if (MODE == MODE_COUNT) {
@@ -1183,6 +1227,53 @@ __global__ __launch_bounds__(256) void combine_classes_kernel(const float* __res
     out[r] = t[0];
 }
 
+// Plan of the split per-hit trace, one wave per 64-ray packet: each ray's chunk counts become
+// output offsets (exclusive scan along the chunks, starting at the ray's own offset), and the
+// packet's chunks are cut into `split` contiguous ranges of about equal hit totals.
+__global__ __launch_bounds__(64) void hits_plan_kernel(const int* __restrict__ chunk_counts,
+                                                       const int* __restrict__ ray_offsets,
+                                                       const uint32_t* __restrict__ perm, int n_rays,
+                                                       int n_chunks, int split,
+                                                       int* __restrict__ chunk_off,
+                                                       int* __restrict__ part_bounds)
+{
+    __shared__ unsigned long long s_total[MAX_HIT_CHUNKS + 1];   // inclusive prefix of the packet's chunk totals
+    const int packet = blockIdx.x, lane = threadIdx.x;
+    const int slot = packet * 64 + lane;
+    const bool valid = slot < n_rays;
+    const int ray = valid ? (perm ? int(perm[slot]) : slot) : 0;
+    int off = valid ? ray_offsets[ray] : 0;
+    unsigned long long run = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int cnt = valid ? chunk_counts[size_t(ray) * n_chunks + c] : 0;
+        if (valid) chunk_off[size_t(ray) * n_chunks + c] = off;
+        off += cnt;
+        unsigned long long t = (unsigned long long)cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        run += t;
+        if (lane == 0) s_total[c] = run;
+    }
+    __syncthreads();
+    // Boundary k = first chunk whose inclusive prefix reaches k/split of the total.
+    if (lane <= split) {
+        int b;
+        if (lane == 0) b = 0;
+        else if (lane == split) b = n_chunks;
+        else {
+            const unsigned long long want = (run * (unsigned long long)lane + split - 1) / split;
+            int lo = 0, hi = n_chunks - 1;           // smallest c with s_total[c] >= want
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_total[mid] >= want) hi = mid; else lo = mid + 1;
+            }
+            b = lo + 1;                               // chunks [.., lo] belong to the parts before
+            if (b > n_chunks) b = n_chunks;
+        }
+        part_bounds[packet * (split + 1) + lane] = b;
+    }
+}
+
 int g_split = -1; // waves per packet; -1: automatic
 int g_width = -1; // rays per packet of the per-hit / triangle traces; -1: automatic
 bool g_exact_integrals = false; // column-density trace: bit-reproducible per-hit arithmetic
@@ -1196,10 +1287,27 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     GRACE_REQUIRE(n_nodes >= 1 && n_nodes < (size_t(1) << 30), "trace: bad node count");
     GRACE_REQUIRE(n_spheres > 0, "trace: no primitives");
     GRACE_TRY(ensure_status(stream));
+    // Split per-hit trace for small batches (see TraceArgs / hits_plan_kernel): chunk size =
+    // a power of two >= one granule giving at most MAX_HIT_CHUNKS chunks.
+    int hit_chunk_shift = GRANULE_SHIFT;
+    while ((((n_spheres - 1) >> hit_chunk_shift) + 1) > size_t(MAX_HIT_CHUNKS)) ++hit_chunk_shift;
+    const int hit_chunks = int(((n_spheres - 1) >> hit_chunk_shift) + 1);
+    const size_t hit_packets = ceil_div(n_rays, size_t(64));
+    int hit_split = 1;
+    if (MODE == MODE_HITS && g_width <= 0 && hit_packets < 4096 && hit_chunks >= 8) {
+        if (g_split > 0) hit_split = g_split;
+        else while (hit_split < 8 && hit_packets * hit_split < 16384) hit_split *= 2;
+    }
+    const bool hits_split = hit_split > 1;
+    int* chunk_counts = nullptr; int* chunk_off = nullptr; int* part_bounds = nullptr;
+    int* scratch_counts = nullptr;
     {
         constexpr bool need_b = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
         const bool reorder = g_ray_reorder && n_rays > 64;
         GRACE_TRY(Workspace::begin(Workspace::aligned((n_spheres + 4) * sizeof(float4))
+                                   + (hits_split ? 2 * Workspace::aligned(n_rays * size_t(hit_chunks) * 4)
+                                                   + Workspace::aligned(hit_packets * (hit_split + 1) * 4)
+                                                   + Workspace::aligned(n_rays * 4) : 0)
                                    + Workspace::aligned((n_spheres + 4) * sizeof(float2))
                                    + Workspace::aligned(n_nodes * sizeof(int2))
                                    + (MODE == MODE_TRI ? Workspace::aligned(72 * (n_spheres + 4)) : 0)
@@ -1211,6 +1319,12 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         double* T64 = (MODE == MODE_TRI) ? Workspace::take<double>(9 * (n_spheres + 4)) : nullptr;
         a.T64 = T64;
         a.partial = (MODE == MODE_CUMULATIVE) ? Workspace::take<float>(n_rays * SUM_CLASSES) : nullptr;
+        if (hits_split) {
+            chunk_counts = Workspace::take<int>(n_rays * size_t(hit_chunks));
+            chunk_off = Workspace::take<int>(n_rays * size_t(hit_chunks));
+            part_bounds = Workspace::take<int>(hit_packets * (hit_split + 1));
+            scratch_counts = Workspace::take<int>(n_rays);
+        }
         int2* node_prims = Workspace::take<int2>(n_nodes);
         node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
             reinterpret_cast<const int4*>(a.nodes), a.leaves, int(n_nodes), node_prims);
@@ -1259,7 +1373,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     // 2-4x the waves, each with a tighter beam, on a chip that would otherwise sit idle.
     int width = 64;
     if (g_width > 0) width = g_width;
-    else if (MODE == MODE_HITS || MODE == MODE_TRI)
+    else if ((MODE == MODE_HITS && !hits_split) || MODE == MODE_TRI)
         while (width > 16 && ceil_div(n_rays, size_t(width)) < 4096) width /= 2;
     a.width = width;
     const int n_packets = ceil_div(n_rays, size_t(width));
@@ -1269,8 +1383,14 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         if (g_split > 0) split = g_split;
         else while (split < SUM_CLASSES && size_t(n_packets) * split < 16384) split *= 2;
     }
+    if (hits_split) split = hit_split;
     a.split = split;
     a.n_prims = int(n_spheres);
+    a.chunk_shift = hit_chunk_shift;
+    a.n_chunks = hit_chunks;
+    a.chunk_counts = nullptr;
+    a.chunk_off = chunk_off;
+    a.part_bounds = part_bounds;
     if (split > 1 && MODE == MODE_COUNT)
         GRACE_TRY_HIP(hipMemsetAsync(a.out_counts, 0, n_rays * sizeof(int), stream));
     if (g_timing) {
@@ -1290,8 +1410,27 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             else trace_kernel<MODE, false, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
         }
     } else if constexpr (MODE == MODE_HITS) {
-        if (n_packets >= 4096) trace_kernel<MODE, false, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
-        else trace_kernel<MODE, false, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        if (hits_split) {
+            // 1. hits per (ray, chunk): the counting walk, split by summation class
+            TraceArgs c = a;
+            c.chunk_counts = chunk_counts;
+            c.out_counts = scratch_counts;
+            GRACE_TRY_HIP(hipMemsetAsync(chunk_counts, 0, n_rays * size_t(hit_chunks) * 4, stream));
+            GRACE_TRY_HIP(hipMemsetAsync(scratch_counts, 0, n_rays * 4, stream));
+            trace_kernel<MODE_COUNT, true><<<grid, TRACE_BLOCK, 0, stream>>>(c);
+            GRACE_CHECK_LAUNCH();
+            // 2. output offsets per (ray, chunk); each packet's chunks cut into `split` ranges
+            hits_plan_kernel<<<n_packets, 64, 0, stream>>>(chunk_counts, a.offsets, a.perm,
+                                                           int(n_rays), hit_chunks, split, chunk_off,
+                                                           part_bounds);
+            GRACE_CHECK_LAUNCH();
+            // 3. the per-hit walk, wave (packet, part) owning its range of chunks
+            trace_kernel<MODE, true, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        } else if (n_packets >= 4096) {
+            trace_kernel<MODE, false, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        } else {
+            trace_kernel<MODE, false, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        }
     } else if constexpr (MODE == MODE_COUNT) {
         if (split > 1) trace_kernel<MODE, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
         else trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
