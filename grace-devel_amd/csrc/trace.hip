@@ -11,53 +11,39 @@
 // every ray meets its hits in ascending primitive index); every ray of the packet is
 // tested against every sphere of every leaf the packet enters.  Results per ray therefore
 // equal the brute-force loop over all spheres (the reference's own criterion,
-// tests/tree_traversal/tree_traversal.cu:65-100) and the fp32 sums are formed in the same
-// order.
+// tests/tree_traversal/tree_traversal.cu:65-100).
 //
-// CDNA4 design (not the reference's):
-//   * packet = one 64-lane wavefront (the reference: a 32-thread warp);
+// CDNA4 design (not the reference's; measurements in DESIGN.md section 4/6):
+//   * packet = one 64-lane wavefront (the reference: a 32-thread warp); for the per-hit and
+//     triangle walks of small batches, 32 or 16 rays per wave;
 //   * the packet's stack lives in TWO VGPRs indexed by lane (pop = v_readlane, push =
-//     lane-select, with a scalar stack pointer): 128 entries, no LDS traffic, no bank conflicts;
-//   * every BVH node, leaf record and sphere is wave-uniform, so it is fetched by the
-//     SCALAR unit (s_load_dwordx4/x16 through the scalar data cache) and the box / sphere
-//     tests run on the VALU with SGPR operands: no per-lane address VGPRs, no texture
-//     path, no LDS staging of leaf spheres (reference: 4 tex1Dfetch + a shared-memory tile);
-//   * the "any lane hit" votes are the SGPR-pair results of v_cmp (free ballots);
-//   * the 51-entry fp64 kernel-integral table is expanded to (y0, y1 - y0) pairs in LDS:
-//     one ds_read_b128 per hit, and the fp64 FMA of the reference's lerp.
-//   * no FMA contraction anywhere (-ffp-contract=off), IEEE 1/x and sqrt: the reference's
-//     CPU/GPU equality test is built with -fmad=false (tests/tree_traversal/Makefile:5-8).
-//   * a streaming pre-pass hoists everything that depends only on the sphere out of the
-//     (ray x sphere) loop: A[i] = {x, y, z, h*h}, B[i] = {1/h, (1/h)^2} -- the same fp32
-//     operations the reference performs per hit, done once per sphere;
-//   * leaf spheres are consumed in chunks of four (one s_load_dwordx16 + one
-//     s_load_dwordx8) with the next chunk's loads issued before the current chunk is
-//     processed; while a leaf is processed the next stack entry's cache line is touched
-//     so that the following pop finds it in the scalar cache;
-//   * beam culling: once per packet the bounding boxes of the 64 origins and 64 directions
-//     are reduced across the wave; at a leaf, lane j takes sphere j and bounds, by interval
-//     arithmetic over the whole beam, the smallest impact parameter any ray of the packet can
-//     have (minus a rounding margin far larger than the fp32 error of sphere_hit).  Spheres
-//     that no ray of the packet can hit are dropped with ONE vector test per leaf; only the
-//     survivors (ballot mask, s_ff1) get the 64-ray test.  Per-ray results are unchanged:
-//     a dropped sphere is one for which sphere_hit is false for every ray of the packet;
-//   * treelet sweep: a node whose subtree holds <= 64 primitives (their indices are
-//     contiguous) is not descended: its primitives go through one beam-culling pass as if
-//     they were a single leaf -- two to three levels of per-ray box tests and leaf records
-//     are replaced by one vector test.  Visiting order (ascending primitive index) and
-//     per-ray results are unchanged; the instrumented `stats` walk never uses it;
-//   * axis-aligned packets (every ray of the packet has the same direction +-e_k: the
-//     orthographic projections of tests/project_gadget, tests/integrate*): sphere_hit's
-//     arithmetic collapses exactly under IEEE rules (x*0 = +-0, y + +-0 = y, p - p = 0):
-//     dot_p = p_k d_k and b2 = q1^2 + q2^2 over the two other components, bit-for-bit the
-//     values of the general expression (a zero dot_p may differ in sign, which no comparison
-//     sees; the per-hit `distances` output keeps the general form).  10 instead of 22 vector
-//     instructions per candidate sphere;
-//   * LDS-staged candidate tiles: the 64 candidates of a culling round are written once to the
-//     wave's LDS tile; survivors are broadcast-read from it into VGPRs one survivor ahead.
-//     That keeps scalar-memory round trips and their address arithmetic out of the inner
-//     loop, lets the sphere test run on VGPR operands (2.6 instead of 4.3 cycles per
-//     instruction on gfx950) and decouples the table lookup's LDS wait from prefetches;
+//     lane-select, with a scalar stack pointer): 128 entries, no LDS traffic;
+//   * node records are wave-uniform: child indices / primitive spans are consumed as scalars,
+//     the per-ray slab test keeps the reference's arithmetic (~320 node tests per packet);
+//   * no FMA contraction (-ffp-contract=off), IEEE 1/x and sqrt in everything that decides a
+//     hit or feeds a bit-exact output: the reference's CPU/GPU equality test is built with
+//     -fmad=false (tests/tree_traversal/Makefile:5-8).  Explicit FMAs appear only where they
+//     provably return the unfused bits (axis dot product), in culls, and in the fast integral;
+//   * a streaming pre-pass hoists per-sphere work out of the (ray x sphere) loop:
+//     A[i] = {x, y, z, h*h}, B[i] = {1/h or 50/h, (1/h)^2};
+//   * ray coherence order: 64 consecutive rays of a space-filling order of the ray
+//     co-ordinates that vary (15-bit round-to-nearest keys; octahedral 2-D order for
+//     partial-sphere bundles from one origin) form a packet; results do not depend on it;
+//   * treelet sweep: a node whose subtree holds <= T primitives (contiguous indices; T = 512
+//     or 256) is not descended: its primitives go through culling rounds of 64;
+//   * beam culling per round, lane j deciding for candidate j whether ANY ray of the packet
+//     can hit it: exact lower bound of b^2 for axis-aligned packets (rounding is monotone),
+//     cone + four side planes for packets from one origin, interval arithmetic otherwise;
+//   * survivors of a round are written compacted (slot = v_mbcnt) to the wave's LDS tile as
+//     three 8-byte planes and read back two survivors ahead into three rotating register sets
+//     (unconditional reads pinned by sched_barrier; immediates address the slots);
+//   * axis-aligned packets (orthographic projections): sphere_hit collapses exactly under IEEE
+//     rules to dot = fma(s_k, d_k, -o_k d_k), b2 = q1^2 + q2^2; rounds whose candidates are
+//     provably inside every ray's [0, length) skip the range tests (6 instructions per test);
+//   * kernel integral of the column-density trace: hardware sqrt + fp32 lerp of an fp32
+//     (y, dy) table in LDS (7 instructions, tolerance parity) by default; the reference's
+//     arithmetic bit for bit (correctly rounded sqrt, fp64 lerp) on request and always for
+//     the per-hit outputs;
 //   * class-ordered sums and packet splitting: primitives are dealt to 8 CLASSES in granules
 //     of 1024 consecutive indices (class = (index >> 10) & 7).  A ray's column density is
 //     defined as the balanced pairwise (binary-tree) fp32 sum of its 8 class sums, each class
@@ -69,13 +55,11 @@
 //     tree, and, because classes interleave along the Morton order, an even share of the
 //     work for any beam -- with NO change of the result: each wave reduces its classes, a
 //     tiny kernel finishes the tree.  K is the smallest power of two that puts >= 16384 waves
-//     in flight (measured: K = 1 for the full 1024^2 image; an eighth of it on one of eight
-//     GPUs runs 30 % faster with K = 2..8, and 10^5 isotropic source rays through 10^6 spheres
-//     3.6x faster with K = 8: one wave per packet leaves the SIMDs idle there).  A wave
-//     keeps its class accumulators in LDS (8 classes: 2 KiB per wave, so that LDS does not cap
-//     occupancy below the VGPR limit of 8 waves/SIMD) and switches at granule boundaries, once
-//     per culling round at most (the walk meets primitives in ascending order).  Hit counts
-//     split the same way (integers);
+//     in flight.  A wave keeps its class accumulators in LDS (2 KiB) and switches at granule
+//     boundaries, once per culling round at most.  Hit counts split the same way (integers);
+//   * per-hit outputs (ordered per ray): large batches stage hits per lane in LDS and drain
+//     them eight entries per ray; small batches split a packet over K waves by contiguous
+//     chunk ranges with per-(ray, chunk) output offsets from a counting walk (hits_plan_kernel);
 //   * packets are dealt to workgroups so that the workgroups sharing an XCD (blockIdx % 8)
 //     walk a contiguous range of packets: neighbouring packets touch the same subtree and
 //     each XCD's 4 MiB L2 keeps it.
