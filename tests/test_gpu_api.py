@@ -281,18 +281,30 @@ def test_sort_by_distance(gh, oracle, cuda):
         assert np.all(np.diff(d1[a:b]) >= 0)
 
 
-def test_sort_by_distance_random_segments(gh, cuda):
+@pytest.mark.parametrize("case", ["many-short", "few-long", "huge"])
+def test_sort_by_distance_random_segments(gh, cuda, case):
+    """Both implementations behind sort_by_distance: one wavefront per segment (mean segment
+    length <= 32768, here with segments from 0 to 40 000 elements, negative zeros and negative
+    distances) and the composite-key global sort ("huge": mean length above that)."""
     rng = np.random.default_rng(4)
-    sizes = rng.integers(0, 300, 5000); sizes[::9] = 0
+    if case == "many-short":
+        sizes = rng.integers(0, 300, 5000); sizes[::9] = 0
+    elif case == "few-long":
+        sizes = np.array([40000, 0, 1, 2, 63, 64, 65, 12345, 0, 30000, 7])
+    else:
+        sizes = np.array([70000, 0, 90000])
     offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
     n = int(sizes.sum())
     dist = rng.integers(0, 50, n).astype(np.float32) * 0.25     # many ties
+    if case != "many-short":
+        dist = (rng.integers(-2000, 2000, n).astype(np.float32) * 0.125)
+        dist[rng.integers(0, n, 50)] = -0.0
     idx = np.arange(n, dtype=np.int32); data = rng.standard_normal(n).astype(np.float32)
     dd = _dev(dist, cuda); di = _dev(idx, cuda); dw = _dev(data, cuda)
     gh.sort_by_distance(dd, _dev(offs, cuda), di, dw)
     seg = np.repeat(np.arange(len(sizes)), sizes)
     order = np.lexsort((np.arange(n), dist, seg))                 # stable within segments
-    assert np.array_equal(dd.cpu().numpy(), dist[order])
+    assert np.array_equal(dd.cpu().numpy().view(np.uint32), dist[order].view(np.uint32))
     assert np.array_equal(di.cpu().numpy(), idx[order])
     assert np.array_equal(dw.cpu().numpy(), data[order])
 
