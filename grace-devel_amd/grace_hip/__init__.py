@@ -316,6 +316,8 @@ def trace_sph(rays, spheres, tree):
     idx = torch.empty(total, dtype=torch.int32, device=rays.device)
     integrals = torch.empty(total, dtype=torch.float32, device=rays.device)
     dists = torch.empty(total, dtype=torch.float32, device=rays.device)
+    if total == 0:             # no ray hits anything: empty outputs, like the reference's resize(0)
+        return offsets, idx, integrals, dists
     _check(_lib.grace_trace_hits_f4(*_trace_args(rays, spheres, tree), _ptr(offsets), _ptr(idx),
                                     _ptr(integrals), _ptr(dists), _stream()))
     return offsets, idx, integrals, dists

@@ -328,6 +328,7 @@ inline void trace_sph(const device_vector<Ray>& d_rays, const device_vector<floa
     d_hit_integrals.resize(size_t(total));
     d_hit_indices.resize(size_t(total));
     d_hit_distances.resize(size_t(total));
+    if (total == 0) return;   // no ray hits anything: empty vectors, as thrust's resize(0)
     detail::check(grace_trace_hits_f4(d_rays.data(), d_rays.size(), &d_spheres.data()->x,
                                       d_spheres.size(), &d_tree.nodes.data()->x,
                                       d_tree.leaves.size() - 1, &d_tree.leaves.data()->x,
