@@ -947,21 +947,28 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     mine_next = pa[nj < leaf.y ? nj : base + 64];
                     if (LDS_TILE && NEED_B) mineb_next = pb[nj < leaf.y ? nj : base + 64];
                 }
-                bool keep;
-                if constexpr (AX >= 0) keep = lane < m && axis_beam_may_hit<AX>(mine, beam);
-                else if constexpr (AX == -2) keep = lane < m && pencil_may_hit(mine, s_pencil[threadIdx.x >> 6]);
-                else keep = lane < m && beam_may_hit(mine, beam);
+                // (The tests run on every lane -- idle lanes hold a clamped, valid candidate -- so
+                // there is no control flow; lane masks are formed from ballots of the bare
+                // comparisons and combined on the scalar unit: a ballot of a combined boolean
+                // costs two extra vector instructions each.)
+                bool may_hit;
+                if constexpr (AX >= 0) may_hit = axis_beam_may_hit<AX>(mine, beam);
+                else if constexpr (AX == -2) may_hit = pencil_may_hit(mine, s_pencil[threadIdx.x >> 6]);
+                else may_hit = beam_may_hit(mine, beam);
+                const unsigned long long m_mask = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
+                unsigned long long rest = __builtin_amdgcn_ballot_w64(may_hit) & m_mask;
+                const bool keep = may_hit & (lane < m);
                 // Axis packets: if every kept candidate lies inside every ray's [0, length)
                 // along the axis -- decided per candidate with the same FMA the rays use, which
                 // is monotone in its addend -- the round's survivors skip the two range tests.
                 bool lean_round = false;
                 if constexpr (AX >= 0 && (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE)) {
                     const float sa = AX == 0 ? mine.x : AX == 1 ? mine.y : mine.z;
-                    const bool inside = __builtin_fmaf(sa, da0, noda_lo) >= 0.0f
-                                     && __builtin_fmaf(sa, da0, noda_hi) < len_lo;
-                    lean_round = same_sense && __builtin_amdgcn_ballot_w64(keep && !inside) == 0ull;
+                    const unsigned long long inside =
+                        __builtin_amdgcn_ballot_w64(__builtin_fmaf(sa, da0, noda_lo) >= 0.0f)
+                        & __builtin_amdgcn_ballot_w64(__builtin_fmaf(sa, da0, noda_hi) < len_lo);
+                    lean_round = same_sense & ((rest & ~inside) == 0ull);
                 }
-                unsigned long long rest = __builtin_amdgcn_ballot_w64(keep);
 #ifdef GRACE_PACKET_STATS
                 if (MODE == MODE_STATS) { st_leaves += 1; st_tested += __builtin_popcountll(rest); }
 #endif
