@@ -147,10 +147,10 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 // include/grace/cuda/device/intersect.cuh:10-40.  Box corners are wave-uniform (SGPRs).
-__device__ __forceinline__ int aabbs_hit(const float ix, const float iy, const float iz,
-                                         const float ox, const float oy, const float oz,
-                                         const float len, const float4 L, const float4 R,
-                                         const float4 Z)
+__device__ __forceinline__ void aabbs_hit(const float ix, const float iy, const float iz,
+                                          const float ox, const float oy, const float oz,
+                                          const float len, const float4 L, const float4 R,
+                                          const float4 Z, bool& hit_l, bool& hit_r)
 {
     const float bx_L = (L.x - ox) * ix, tx_L = (L.y - ox) * ix;
     const float by_L = (L.z - oy) * iy, ty_L = (L.w - oy) * iy;
@@ -168,8 +168,9 @@ __device__ __forceinline__ int aabbs_hit(const float ix, const float iy, const f
                             imax(imin(__float_as_int(bz_R), __float_as_int(tz_R)), zero));
     const int tmax_R = imin(imin(__float_as_int(fmaxf(bx_R, tx_R)), __float_as_int(fmaxf(by_R, ty_R))),
                             imin(imax(__float_as_int(bz_R), __float_as_int(tz_R)), ilen));
-    return int(__int_as_float(tmax_R) >= __int_as_float(tmin_R))
-         + 2 * int(__int_as_float(tmax_L) >= __int_as_float(tmin_L));
+    // two bare comparisons: their ballots fold onto the v_cmp results
+    hit_r = __int_as_float(tmax_R) >= __int_as_float(tmin_R);
+    hit_l = __int_as_float(tmax_L) >= __int_as_float(tmin_L);
 }
 
 // OnHit_sphere_cumulate / _individual arithmetic (functors/trace.cuh:181-186) with lerp
@@ -893,8 +894,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             // (A wave-uniform box-overlap test of the packet's bounding box -- twelve compares
             // instead of this per-ray slab test -- was tried for axis-aligned packets: same node
             // count, 25 % SLOWER kernel; node tests are only ~320 per packet, 6 % of the VALU work.)
-            const int lr = aabbs_hit(ix, iy, iz, ox, oy, oz, len, L, R, Z);
-            const bool hit_r = lr & 1, hit_l = lr >= 2;
+            bool hit_l, hit_r;
+            aabbs_hit(ix, iy, iz, ox, oy, oz, len, L, R, Z, hit_l, hit_r);
             const unsigned long long vote_r = __builtin_amdgcn_ballot_w64(hit_r);
             const unsigned long long vote_l = __builtin_amdgcn_ballot_w64(hit_l);
 #ifdef GRACE_PACKET_STATS
