@@ -134,7 +134,7 @@ __device__ __forceinline__ void triangle_box(const float* __restrict__ t, float*
     }
 }
 
-enum { PRIM_SPHERE = 0, PRIM_TRIANGLE = 1 };
+enum { PRIM_SPHERE = 0, PRIM_TRIANGLE = 1, PRIM_SPHERE_D4 = 2 };
 
 // Leaf AABBs (albvh.cuh:402-424): eight lanes per leaf stride over its primitives, so a
 // wave reads eight runs of consecutive primitives (128 B each for spheres), then an
@@ -153,7 +153,13 @@ __global__ __launch_bounds__(256) void leaf_boxes_kernel(const float4* __restric
         for (int i = sub; i < leaf.y; i += 8) {
             float b[3], tp[3];
             if (PRIM == PRIM_SPHERE) sphere_box(prims[leaf.x + i], b, tp);
-            else triangle_box(reinterpret_cast<const float*>(prims) + 9 * size_t(leaf.x + i), b, tp);
+            else if (PRIM == PRIM_SPHERE_D4) {
+                // AABBSphere with Real4 = double4 (generic/functors/aabb.h:9-26): centre -+ radius
+                // in double, narrowed to the float corner
+                const double* s = reinterpret_cast<const double*>(prims) + 4 * size_t(leaf.x + i);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { b[c] = float(s[c] - s[3]); tp[c] = float(s[c] + s[3]); }
+            } else triangle_box(reinterpret_cast<const float*>(prims) + 9 * size_t(leaf.x + i), b, tp);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 bot[c] = fminf(bot[c], b[c]);
@@ -472,6 +478,15 @@ grace_status grace_albvh_build_tri_u32(const float* d_tris, size_t n, const uint
 {
     return albvh_build<uint32_t, PRIM_TRIANGLE>(d_tris, n, d_deltas, max_per_leaf, d_nodes,
                                                 d_leaves, d_root, h_n_leaves, as_stream(stream));
+}
+
+grace_status grace_albvh_build_d4(const double* d_spheres, size_t n, const float* d_deltas,
+                                  int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                  size_t* h_n_leaves, grace_stream stream)
+{
+    return albvh_build<float, PRIM_SPHERE_D4>(reinterpret_cast<const float*>(d_spheres), n, d_deltas,
+                                              max_per_leaf, d_nodes, d_leaves, d_root, h_n_leaves,
+                                              as_stream(stream));
 }
 
 grace_status grace_albvh_enable_timing(int enabled)

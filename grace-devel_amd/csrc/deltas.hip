@@ -48,6 +48,21 @@ __global__ __launch_bounds__(256) void sphere_deltas_kernel(const float4* __rest
     if (t < n) deltas[t + 1] = (t + 1 < n) ? sphere_delta<KIND>(a, b) : INFINITY;
 }
 
+// DeltaEuclidean on double4 spheres (generic/functors/albvh.h:44-74): differences and products
+// in double, the sum narrowed to the float the functor returns.  32 B per sphere, two reads.
+__global__ __launch_bounds__(256) void sphere_deltas_d4_kernel(const double* __restrict__ s, size_t n,
+                                                               float* __restrict__ deltas)
+{
+    const size_t t = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (t == 0) deltas[0] = INFINITY;
+    if (t >= n) return;
+    if (t + 1 >= n) { deltas[t + 1] = INFINITY; return; }
+    const double* a = s + 4 * t;
+    const double* b = a + 4;
+    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    deltas[t + 1] = float(dx * dx + dy * dy + dz * dz);
+}
+
 template <typename Key>
 __global__ __launch_bounds__(256) void xor_deltas_kernel(const Key* __restrict__ keys, size_t n,
                                                          Key* __restrict__ deltas)
@@ -77,6 +92,15 @@ grace_status grace_deltas_area_f4(const float* d_spheres, size_t n, float* d_del
     GRACE_REQUIRE(d_spheres && d_deltas && n > 0, "deltas: null pointer or empty input");
     sphere_deltas_kernel<DELTA_AREA><<<ceil_div(n, 256), 256, 0, as_stream(stream)>>>(
         reinterpret_cast<const float4*>(d_spheres), n, d_deltas);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+grace_status grace_deltas_euclid_d4(const double* d_spheres, size_t n, float* d_deltas,
+                                    grace_stream stream)
+{
+    GRACE_REQUIRE(d_spheres && d_deltas && n > 0, "deltas: null pointer or empty input");
+    sphere_deltas_d4_kernel<<<ceil_div(n, 256), 256, 0, as_stream(stream)>>>(d_spheres, n, d_deltas);
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
 }

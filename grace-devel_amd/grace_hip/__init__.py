@@ -539,6 +539,52 @@ def morton_keys_points(points, keys, bot, top):
     return keys
 
 
+# ---------------------------------------------------------------------------------------
+# double4 spheres (Real4 = double4, Real = double)
+# ---------------------------------------------------------------------------------------
+def _spheres_d4(s):
+    assert s.is_cuda and s.is_contiguous() and s.dtype == torch.float64 and s.dim() == 2 and s.shape[1] == 4
+
+
+def build_tree_d4(spheres, tree, bot, top):
+    """tests/helper/tree.cuh build_tree with double4 spheres: 30-bit keys of the float-narrowed
+    centres, sort of the 32-byte records, Euclidean deltas (formed in double, stored as float),
+    ALBVH.  Sorts `spheres` in place."""
+    _spheres_d4(spheres)
+    n = len(spheres)
+    keys = torch.empty(n, dtype=torch.int32, device=spheres.device)
+    morton_keys_points(spheres, keys, bot, top)
+    sort_by_key(keys, spheres, 0, 30)
+    deltas = torch.empty(n + 1, dtype=torch.float32, device=spheres.device)
+    _check(_lib.grace_deltas_euclid_d4(_ptr(spheres), C.c_size_t(n), _ptr(deltas), _stream()))
+    n_leaves = C.c_size_t(0)
+    _check(_lib.grace_albvh_build_d4(_ptr(spheres), C.c_size_t(n), _ptr(deltas),
+                                     C.c_int(tree.max_per_leaf), _ptr(tree.nodes), _ptr(tree.leaves),
+                                     _ptr(tree.root_index), C.byref(n_leaves), _stream()))
+    tree.leaves = tree.leaves[: n_leaves.value]
+    tree.nodes = tree.nodes[: n_leaves.value - 1]
+    return deltas
+
+
+def _trace_args_d4(rays, spheres, tree):
+    _check_rays(rays); _spheres_d4(spheres)
+    return (_ptr(rays), C.c_size_t(len(rays)), _ptr(spheres), C.c_size_t(len(spheres)),
+            _ptr(tree.nodes), C.c_size_t(tree.n_leaves - 1), _ptr(tree.leaves), _ptr(tree.root_index))
+
+
+def trace_hitcounts_d4(rays, spheres, tree, counts):
+    _check(_lib.grace_trace_hitcounts_d4(*_trace_args_d4(rays, spheres, tree), _ptr(counts), _stream()))
+    _check(_lib.grace_trace_status_d4(_stream()))
+    return counts
+
+
+def trace_cumulative_d4(rays, spheres, tree, sums):
+    assert sums.dtype == torch.float64
+    _check(_lib.grace_trace_cumulative_d4(*_trace_args_d4(rays, spheres, tree), _ptr(sums), _stream()))
+    _check(_lib.grace_trace_status_d4(_stream()))
+    return sums
+
+
 def project_sph(spheres, n_side, max_per_leaf=32):
     """The projection of tests/project_gadget/project_gadget.cu:58-81: bounds with
     w = 0, build_tree, orthogonal_rays_z, trace_cumulative_sph.  Sorts spheres in place.

@@ -539,6 +539,54 @@ inline void morton_keys63_sort_sph(device_vector<double4>& d_spheres, const floa
                                        nullptr, nullptr));
 }
 
+// build_sph.cuh:84-93 with Real4 = double4.  The functor returns float whatever Real is
+// (generic/functors/albvh.h:44-74), so the deltas are kept as float here (the reference stores
+// the same values widened into a vector<double>).
+inline void euclidean_deltas_sph(const device_vector<double4>& d_spheres,
+                                 device_vector<float>& d_deltas)
+{
+    detail::check(grace_deltas_euclid_d4(&d_spheres.data()->x, d_spheres.size(), d_deltas.data(),
+                                         nullptr));
+}
+
+// build_sph.cuh:116-126 with Real4 = double4
+inline void ALBVH_sph(const device_vector<double4>& d_spheres, const device_vector<float>& d_deltas,
+                      Tree& d_tree)
+{
+    size_t n_leaves = 0;
+    detail::check(grace_albvh_build_d4(&d_spheres.data()->x, d_spheres.size(), d_deltas.data(),
+                                       d_tree.max_per_leaf, &d_tree.nodes.data()->x,
+                                       &d_tree.leaves.data()->x, d_tree.root_index_ptr, &n_leaves,
+                                       nullptr));
+    d_tree.nodes.resize(4 * (n_leaves - 1));
+    d_tree.leaves.resize(n_leaves);
+}
+
+// trace_sph.cuh:57-110 with Real4 = double4, Real = double
+inline void trace_hitcounts_sph(const device_vector<Ray>& d_rays,
+                                const device_vector<double4>& d_spheres, const Tree& d_tree,
+                                device_vector<int>& d_hit_counts)
+{
+    detail::check_ray_count(d_rays.size());
+    detail::check(grace_trace_hitcounts_d4(d_rays.data(), d_rays.size(), &d_spheres.data()->x,
+                                           d_spheres.size(), &d_tree.nodes.data()->x,
+                                           d_tree.leaves.size() - 1, &d_tree.leaves.data()->x,
+                                           d_tree.root_index_ptr, d_hit_counts.data(), nullptr));
+    detail::check(grace_trace_status_d4(nullptr));
+}
+
+inline void trace_cumulative_sph(const device_vector<Ray>& d_rays,
+                                 const device_vector<double4>& d_spheres, const Tree& d_tree,
+                                 device_vector<double>& d_cumulated)
+{
+    detail::check_ray_count(d_rays.size());
+    detail::check(grace_trace_cumulative_d4(d_rays.data(), d_rays.size(), &d_spheres.data()->x,
+                                            d_spheres.size(), &d_tree.nodes.data()->x,
+                                            d_tree.leaves.size() - 1, &d_tree.leaves.data()->x,
+                                            d_tree.root_index_ptr, d_cumulated.data(), nullptr));
+    detail::check(grace_trace_status_d4(nullptr));
+}
+
 // util/extrema.cuh min_vec4 / max_vec4 as used by tests/project_gadget/project_gadget.cu:66-68
 inline void min_max_vec4(const device_vector<float4>& d_v, float4* mins, float4* maxs)
 {

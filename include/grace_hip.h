@@ -317,6 +317,31 @@ grace_status grace_rays_orthographic_projection(int res_x, int res_y, const floa
                                                 float vertical_extent, float length,
                                                 void* d_rays, grace_stream stream);
 
+/* ---- double4 spheres: the reference's templates with Real4 = double4, Real = double
+ *      (build_sph.cuh:84-126, trace_sph.cuh:57-110).  Keys: grace_morton_keys{30,63}_points;
+ *      sort: grace_sort_pairs_u32/u64 with 32-byte records. -------------------------------- */
+/* euclidean_deltas_sph<double4>: DeltaEuclidean forms the squared distance in double and returns
+ * it as float (generic/functors/albvh.h:44-74); deltas[n + 1] floats, +inf at both ends. */
+grace_status grace_deltas_euclid_d4(const double* d_spheres, size_t n, float* d_deltas,
+                                    grace_stream stream);
+/* ALBVH_sph<double4>: same tree builder; leaf / node boxes are AABBSphere's float3 corners of the
+ * double centre -+ radius (generic/functors/aabb.h:9-26).  Same output layout as _f4. */
+grace_status grace_albvh_build_d4(const double* d_spheres, size_t n, const float* d_deltas,
+                                  int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                  size_t* h_n_leaves, grace_stream stream);
+/* trace_hitcounts_sph / trace_cumulative_sph <double4, double>: sphere_hit and the kernel
+ * integral in double, one running double sum per ray in ascending primitive index.  A compact
+ * kernel (packets of 64 consecutive rays in caller order), not the tuned float path. */
+grace_status grace_trace_hitcounts_d4(const void* d_rays, size_t n_rays, const double* d_spheres,
+                                      size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                      const int* d_leaves, const int* d_root, int* d_hit_counts,
+                                      grace_stream stream);
+grace_status grace_trace_cumulative_d4(const void* d_rays, size_t n_rays, const double* d_spheres,
+                                       size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                       const int* d_leaves, const int* d_root, double* d_sums,
+                                       grace_stream stream);
+grace_status grace_trace_status_d4(grace_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -331,6 +331,11 @@ static void prim_aabb(const float* prims, int kind, size_t i, float* bot, float*
     if (kind == 0) {
         const float* s = prims + 4 * i;
         for (int k = 0; k < 3; ++k) { bot[k] = s[k] - s[3]; top[k] = s[k] + s[3]; }
+    } else if (kind == 2) {
+        /* double4 spheres: AABBSphere with Real4 = double4 (generic/functors/aabb.h:9-26):
+         * the sum is formed in double and narrowed to the float3 corner */
+        const double* s = (const double*)prims + 4 * i;
+        for (int k = 0; k < 3; ++k) { bot[k] = (float)(s[k] - s[3]); top[k] = (float)(s[k] + s[3]); }
     } else {
         const float* t = prims + 9 * i;
         for (int k = 0; k < 3; ++k) {
@@ -1015,6 +1020,74 @@ void go_one_to_many_rays(const void* points, int is_double, int stride, size_t n
         float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         go_ray r = { dx * inv, dy * inv, dz * inv, ox, oy, oz, (float)(1.0 / (double)inv) };
         rays[t] = r;
+    }
+}
+
+/* ---- double4 spheres (Real4 = double4, Real = double; build_sph.cuh:84-126, trace_sph.cuh) -- */
+
+/* DeltaEuclidean on double4 (generic/functors/albvh.h:44-74): differences and products in
+ * double, the sum narrowed to the float it returns; +inf at both ends. */
+void go_deltas_euclid_d4(const double* s, size_t n, float* out)
+{
+    out[0] = INFINITY; out[n] = INFINITY;
+    for (size_t i = 0; i + 1 < n; ++i) {
+        const double* a = s + 4 * i; const double* b = s + 4 * (i + 1);
+        out[i + 1] = (float)((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1])
+                             + (a[2] - b[2]) * (a[2] - b[2]));
+    }
+}
+
+/* sphere_hit<double4, double> (generic/intersect.h:9-55): ray members are float, everything
+ * else double. */
+static inline int sphere_hit_d(const go_ray* ray, const double* s, double* b2, double* dot_p)
+{
+    double px = s[0] - ray->ox, py = s[1] - ray->oy, pz = s[2] - ray->oz;
+    double rx = ray->dx, ry = ray->dy, rz = ray->dz;
+    *dot_p = px * rx + py * ry + pz * rz;
+    double bx = px - *dot_p * rx, by = py - *dot_p * ry, bz = pz - *dot_p * rz;
+    *b2 = bx * bx + by * by + bz * bz;
+    if (*b2 >= s[3] * s[3]) return 0;
+    if (*dot_p < 0.0f) return 0;
+    if (*dot_p >= ray->length) return 0;
+    return 1;
+}
+
+/* OnHit_sphere_cumulate with Real = double (functors/trace.cuh:164-186) and lerp<double>
+ * (generic/interpolate.h:11-39, device branch: fma). */
+static inline double hit_integral_d(double b2, double w)
+{
+    double ir = 1.f / w;
+    double x = (GO_N_TABLE - 1) * (sqrt(b2) * ir);
+    int x_idx = (int)x;
+    if (x_idx >= GO_N_TABLE - 1) { x = (double)(GO_N_TABLE - 1); x_idx = GO_N_TABLE - 2; }
+    double y0 = go_table[x_idx], y1 = go_table[x_idx + 1];
+    double t = x - x_idx;
+    double integral = fma(t, y1 - y0, y0);
+    integral *= (ir * ir);
+    return integral;
+}
+
+void go_brute_hitcounts_d4(const go_ray* rays, size_t n_rays, const double* s, size_t n, int* counts)
+{
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (size_t ri = 0; ri < n_rays; ++ri) {
+        go_ray ray = rays[ri];
+        int hits = 0; double b2, d;
+        for (size_t si = 0; si < n; ++si) hits += sphere_hit_d(&ray, s + 4 * si, &b2, &d);
+        counts[ri] = hits;
+    }
+}
+
+/* One running double sum per ray in ascending primitive index (RayData_sphere<double,double>). */
+void go_brute_cumulative_d4(const go_ray* rays, size_t n_rays, const double* s, size_t n, double* out)
+{
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (size_t ri = 0; ri < n_rays; ++ri) {
+        go_ray ray = rays[ri];
+        double acc = 0.0, b2, d;
+        for (size_t si = 0; si < n; ++si)
+            if (sphere_hit_d(&ray, s + 4 * si, &b2, &d)) acc += hit_integral_d(b2, s[4 * si + 3]);
+        out[ri] = acc;
     }
 }
 

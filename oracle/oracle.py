@@ -161,7 +161,7 @@ _SUFFIX = {np.dtype(np.float32): "f32", np.dtype(np.uint32): "u32", np.dtype(np.
 
 def albvh(prims, deltas, max_per_leaf, prim_kind=0):
     """Returns (nodes[n_nodes,16] as int32 view, leaves[n_leaves,4], root)."""
-    prims = np.ascontiguousarray(prims, np.float32)
+    prims = np.ascontiguousarray(prims, np.float64 if prim_kind == 2 else np.float32)
     deltas = np.ascontiguousarray(deltas)
     sfx = _SUFFIX[deltas.dtype]
     n = len(prims)
@@ -350,4 +350,27 @@ def one_to_many_rays(origin, points):
                               C.c_float(origin[0]), C.c_float(origin[1]), C.c_float(origin[2]),
                               _p(rays))
     return rays
+
+
+# -- double4 spheres (Real4 = double4, Real = double) ------------------------------------------
+
+def deltas_euclid_d4(prims):
+    prims = np.ascontiguousarray(prims, np.float64)
+    out = np.empty(len(prims) + 1, np.float32)
+    lib().go_deltas_euclid_d4(_p(prims), C.c_size_t(len(prims)), _p(out))
+    return out
+
+
+def brute_hitcounts_d4(rays, prims):
+    rays = _rays(rays); prims = np.ascontiguousarray(prims, np.float64)
+    out = np.empty(len(rays), np.int32)
+    lib().go_brute_hitcounts_d4(_p(rays), C.c_size_t(len(rays)), _p(prims), C.c_size_t(len(prims)), _p(out))
+    return out
+
+
+def brute_cumulative_d4(rays, prims):
+    rays = _rays(rays); prims = np.ascontiguousarray(prims, np.float64)
+    out = np.empty(len(rays), np.float64)
+    lib().go_brute_cumulative_d4(_p(rays), C.c_size_t(len(rays)), _p(prims), C.c_size_t(len(prims)), _p(out))
+    return out
 

@@ -93,6 +93,34 @@ int main()
     for (size_t i = 1; i < k.size(); ++i) bad += k[i] < k[i - 1];
     EXPECT(bad == 0);
 
+    // double4 build + trace through the mirror: tree over the sorted records, counts consistent
+    // with the column densities (a ray has a positive sum iff it has hits)
+    {
+        std::vector<double4> hs(20000);
+        for (size_t i = 0; i < hs.size(); ++i) {
+            hs[i].x = 0.5 + 0.5 * std::sin(12.9898 * i); hs[i].y = 0.5 + 0.5 * std::sin(78.233 * i + 1.0);
+            hs[i].z = 0.5 + 0.5 * std::sin(37.719 * i + 2.0); hs[i].w = 0.01 + 0.02 * (i % 7) / 7.0;
+        }
+        device_vector<double4> d_sph(hs);
+        const float3 lo = make_float3(0, 0, 0), hi = make_float3(1, 1, 1);
+        morton_keys30_sort_sph(d_sph, lo, hi);
+        device_vector<float> d_del(hs.size() + 1);
+        euclidean_deltas_sph(d_sph, d_del);
+        Tree tree(hs.size(), 16);
+        ALBVH_sph(d_sph, d_del, tree);
+        device_vector<Ray> d_r(512);
+        uniform_random_rays(d_r, 0.5f, 0.5f, 0.5f, 2.f, 5);
+        device_vector<int> d_c(512);
+        device_vector<double> d_s(512);
+        trace_hitcounts_sph(d_r, d_sph, tree, d_c);
+        trace_cumulative_sph(d_r, d_sph, tree, d_s);
+        const std::vector<int> c = d_c.to_host();
+        const std::vector<double> sm = d_s.to_host();
+        bad = 0; long total = 0;
+        for (size_t i = 0; i < c.size(); ++i) { bad += (c[i] > 0) != (sm[i] > 0.0); total += c[i]; }
+        EXPECT(bad == 0 && total > 1000);
+    }
+
     std::printf(fails ? "FAILED\n" : "PASSED\n");
     return fails ? EXIT_FAILURE : EXIT_SUCCESS;
 }
