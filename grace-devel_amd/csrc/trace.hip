@@ -892,8 +892,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                 sweep = true; sweep_first = span.x; sweep_count = span.y;
             } else {
             // (A wave-uniform box-overlap test of the packet's bounding box -- twelve compares
-            // instead of this per-ray slab test -- was tried for axis-aligned packets: same node
-            // count, 25 % SLOWER kernel; node tests are only ~320 per packet, 6 % of the VALU work.)
+            // instead of this per-ray slab test -- was tried twice for axis-aligned packets: same
+            // node count, no gain (node tests are ~320 per packet, ~12 % of the vector work).)
             bool hit_l, hit_r;
             aabbs_hit(ix, iy, iz, ox, oy, oz, len, L, R, Z, hit_l, hit_r);
             const unsigned long long vote_r = __builtin_amdgcn_ballot_w64(hit_r);
