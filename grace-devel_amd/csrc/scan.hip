@@ -225,23 +225,36 @@ __device__ __forceinline__ size_t lower_bound_i32(const int* __restrict__ a, siz
     return lo;
 }
 
-// Head flags of one 1024-element chunk into LDS, from CSR offsets (level 0) or from an
-// explicit per-element flag array (spine levels).
+// table[b] = index of the first segment starting at or after slab b's first element, for
+// b = 0 .. n_slabs: one thread per slab, so the binary searches over the offsets run in
+// parallel once instead of serially in every workgroup (they used to be two dependent chains
+// of ~17 global loads per 1024-element chunk, which bounded the scan).
+__global__ __launch_bounds__(256) void seg_slab_bounds_kernel(const int* __restrict__ offsets,
+                                                              size_t n_seg, size_t n_slabs,
+                                                              uint32_t* __restrict__ table)
+{
+    const size_t b = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
+    if (b <= n_slabs) table[b] = uint32_t(lower_bound_i32(offsets, n_seg, (long long)(b * SCAN_SLAB)));
+}
+
+// Head flags of one 8192-element slab into LDS, from CSR offsets (level 0; the slab's range of
+// segments comes from `table`) or from an explicit per-element flag array (spine levels).
 template <bool FROM_OFFSETS>
-__device__ __forceinline__ void load_heads(unsigned char* s_head, size_t chunk0, size_t n,
-                                           const int* __restrict__ offsets, size_t n_seg,
+__device__ __forceinline__ void load_heads(unsigned char* s_head, size_t slab0, size_t n,
+                                           const int* __restrict__ offsets,
+                                           const uint32_t* __restrict__ table,
                                            const unsigned char* __restrict__ flags)
 {
-    for (int k = threadIdx.x; k < SCAN_CHUNK; k += SCAN_BLOCK)
-        s_head[k] = (!FROM_OFFSETS && chunk0 + k < n) ? flags[chunk0 + k] : 0;
     if (FROM_OFFSETS) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(s_head);
+        for (int k = threadIdx.x; k < SCAN_SLAB / 4; k += SCAN_BLOCK) w[k] = 0u;
         __syncthreads();
-        const size_t s0 = lower_bound_i32(offsets, n_seg, (long long)chunk0);
-        const size_t s1 = lower_bound_i32(offsets, n_seg, (long long)chunk0 + SCAN_CHUNK);
-        for (size_t s = s0 + threadIdx.x; s < s1; s += SCAN_BLOCK) {
-            const long long o = offsets[s];
-            s_head[o - (long long)chunk0] = 1;
-        }
+        const size_t s0 = table[blockIdx.x], s1 = table[blockIdx.x + 1];
+        for (size_t s = s0 + threadIdx.x; s < s1; s += SCAN_BLOCK)
+            s_head[(long long)offsets[s] - (long long)slab0] = 1;
+    } else {
+        for (int k = threadIdx.x; k < SCAN_SLAB; k += SCAN_BLOCK)
+            s_head[k] = slab0 + k < n ? flags[slab0 + k] : 0;
     }
     __syncthreads();
 }
@@ -249,18 +262,19 @@ __device__ __forceinline__ void load_heads(unsigned char* s_head, size_t chunk0,
 // Upsweep: per slab, (has a head, sum of the elements after the slab's last head).
 template <typename T, bool FROM_OFFSETS>
 __global__ __launch_bounds__(SCAN_BLOCK) void seg_reduce_kernel(
-    const T* __restrict__ data, size_t n, const int* __restrict__ offsets, size_t n_seg,
-    const unsigned char* __restrict__ flags, T* __restrict__ agg_v,
-    unsigned char* __restrict__ agg_f)
+    const T* __restrict__ data, size_t n, const int* __restrict__ offsets,
+    const uint32_t* __restrict__ table, const unsigned char* __restrict__ flags,
+    T* __restrict__ agg_v, unsigned char* __restrict__ agg_f)
 {
-    __shared__ unsigned char s_head[SCAN_CHUNK];
+    __shared__ __align__(4) unsigned char s_slab_head[SCAN_SLAB];
     __shared__ SegPair<T> s_wave[SCAN_BLOCK / 64];
     const size_t slab0 = size_t(blockIdx.x) * SCAN_SLAB;
+    load_heads<FROM_OFFSETS>(s_slab_head, slab0, n, offsets, table, flags);
     SegPair<T> carry; carry.v = T(0); carry.f = 0;
     for (int c = 0; c < SCAN_CHUNKS_PER_SLAB; ++c) {
         const size_t chunk0 = slab0 + size_t(c) * SCAN_CHUNK;
         if (chunk0 >= n) break;
-        load_heads<FROM_OFFSETS>(s_head, chunk0, n, offsets, n_seg, flags);
+        const unsigned char* s_head = s_slab_head + c * SCAN_CHUNK;
         const size_t i = chunk0 + threadIdx.x * SCAN_VEC;
         SegPair<T> p; p.v = T(0); p.f = 0;
 #pragma unroll
@@ -286,17 +300,19 @@ __global__ __launch_bounds__(SCAN_BLOCK) void seg_reduce_kernel(
 // since the last head before i (heads are not reset first) = the carry into slab i.
 template <typename T, bool FROM_OFFSETS, bool CARRY_MODE>
 __global__ __launch_bounds__(SCAN_BLOCK) void seg_scan_kernel(
-    const T* data, T* out, size_t n, const int* __restrict__ offsets, size_t n_seg,
-    const unsigned char* __restrict__ flags, const T* __restrict__ carry_in)
+    const T* data, T* out, size_t n, const int* __restrict__ offsets,
+    const uint32_t* __restrict__ table, const unsigned char* __restrict__ flags,
+    const T* __restrict__ carry_in)
 {
-    __shared__ unsigned char s_head[SCAN_CHUNK];
+    __shared__ __align__(4) unsigned char s_slab_head[SCAN_SLAB];
     __shared__ SegPair<T> s_wave[SCAN_BLOCK / 64];
     const size_t slab0 = size_t(blockIdx.x) * SCAN_SLAB;
+    load_heads<FROM_OFFSETS>(s_slab_head, slab0, n, offsets, table, flags);
     SegPair<T> carry; carry.v = carry_in ? carry_in[blockIdx.x] : T(0); carry.f = 0;
     for (int c = 0; c < SCAN_CHUNKS_PER_SLAB; ++c) {
         const size_t chunk0 = slab0 + size_t(c) * SCAN_CHUNK;
         if (chunk0 >= n) break;
-        load_heads<FROM_OFFSETS>(s_head, chunk0, n, offsets, n_seg, flags);
+        const unsigned char* s_head = s_slab_head + c * SCAN_CHUNK;
         const size_t i = chunk0 + threadIdx.x * SCAN_VEC;
         T v[SCAN_VEC]; int h[SCAN_VEC];
         SegPair<T> p; p.v = T(0); p.f = 0;
@@ -347,19 +363,19 @@ grace_status seg_spine(T* d_v, const unsigned char* d_f, size_t n, hipStream_t s
 {
     const size_t n_slabs = (n + SCAN_SLAB - 1) / SCAN_SLAB;
     if (n_slabs == 1) {
-        seg_scan_kernel<T, false, true><<<1, SCAN_BLOCK, 0, stream>>>(d_v, d_v, n, nullptr, 0,
-                                                                      d_f, nullptr);
+        seg_scan_kernel<T, false, true><<<1, SCAN_BLOCK, 0, stream>>>(d_v, d_v, n, nullptr,
+                                                                      nullptr, d_f, nullptr);
         GRACE_CHECK_LAUNCH();
         return GRACE_OK;
     }
     T* agg_v = Workspace::take<T>(n_slabs);
     unsigned char* agg_f = Workspace::take<unsigned char>(n_slabs);
-    seg_reduce_kernel<T, false><<<int(n_slabs), SCAN_BLOCK, 0, stream>>>(d_v, n, nullptr, 0, d_f,
-                                                                         agg_v, agg_f);
+    seg_reduce_kernel<T, false><<<int(n_slabs), SCAN_BLOCK, 0, stream>>>(d_v, n, nullptr, nullptr,
+                                                                         d_f, agg_v, agg_f);
     GRACE_CHECK_LAUNCH();
     GRACE_TRY(seg_spine<T>(agg_v, agg_f, n_slabs, stream));
     seg_scan_kernel<T, false, true><<<int(n_slabs), SCAN_BLOCK, 0, stream>>>(d_v, d_v, n, nullptr,
-                                                                             0, d_f, agg_v);
+                                                                             nullptr, d_f, agg_v);
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
 }
@@ -371,22 +387,26 @@ grace_status segscan(const int* d_offsets, size_t n_seg, const T* d_data, size_t
     GRACE_REQUIRE(n == 0 || (d_data && d_out), "segmented scan: null data");
     GRACE_REQUIRE(n_seg == 0 || d_offsets, "segmented scan: null offsets");
     if (n == 0) return GRACE_OK;
-    GRACE_TRY(Workspace::begin(seg_ws_bytes<T>(n)));
     const size_t n_slabs = (n + SCAN_SLAB - 1) / SCAN_SLAB;
+    GRACE_TRY(Workspace::begin(seg_ws_bytes<T>(n) + Workspace::aligned((n_slabs + 1) * 4)));
+    uint32_t* table = Workspace::take<uint32_t>(n_slabs + 1);
+    seg_slab_bounds_kernel<<<int((n_slabs + 256) / 256), 256, 0, stream>>>(d_offsets, n_seg, n_slabs,
+                                                                            table);
+    GRACE_CHECK_LAUNCH();
     if (n_slabs == 1) {
         seg_scan_kernel<T, true, false><<<1, SCAN_BLOCK, 0, stream>>>(d_data, d_out, n, d_offsets,
-                                                                      n_seg, nullptr, nullptr);
+                                                                      table, nullptr, nullptr);
         GRACE_CHECK_LAUNCH();
         return GRACE_OK;
     }
     T* agg_v = Workspace::take<T>(n_slabs);
     unsigned char* agg_f = Workspace::take<unsigned char>(n_slabs);
     seg_reduce_kernel<T, true><<<int(n_slabs), SCAN_BLOCK, 0, stream>>>(
-        d_data, n, d_offsets, n_seg, nullptr, agg_v, agg_f);
+        d_data, n, d_offsets, table, nullptr, agg_v, agg_f);
     GRACE_CHECK_LAUNCH();
     GRACE_TRY(seg_spine<T>(agg_v, agg_f, n_slabs, stream));
     seg_scan_kernel<T, true, false><<<int(n_slabs), SCAN_BLOCK, 0, stream>>>(
-        d_data, d_out, n, d_offsets, n_seg, nullptr, agg_v);
+        d_data, d_out, n, d_offsets, table, nullptr, agg_v);
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
 }
