@@ -19,6 +19,7 @@ constexpr int SCAN_VEC = 4;                          // items per thread per chu
 constexpr int SCAN_CHUNK = SCAN_BLOCK * SCAN_VEC;    // 1024
 constexpr int SCAN_CHUNKS_PER_SLAB = 8;
 constexpr int SCAN_SLAB = SCAN_CHUNK * SCAN_CHUNKS_PER_SLAB; // 8192 items per workgroup
+static_assert(SCAN_VEC == 4, "the u32 scan kernels move uint4 vectors: SCAN_VEC is not a tuning knob");
 
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, int lane)
 {
