@@ -29,8 +29,8 @@
 //   * ray coherence order: 64 consecutive rays of a space-filling order of the ray
 //     co-ordinates that vary (15-bit round-to-nearest keys; octahedral 2-D order for
 //     partial-sphere bundles from one origin) form a packet; results do not depend on it;
-//   * treelet sweep: a node whose subtree holds <= T primitives (contiguous indices; T = 512
-//     or 256) is not descended: its primitives go through culling rounds of 64;
+//   * treelet sweep: a node whose subtree holds <= T primitives (contiguous indices; T = 512)
+//     is not descended: its primitives go through culling rounds of 64;
 //   * beam culling per round, lane j deciding for candidate j whether ANY ray of the packet
 //     can hit it: exact lower bound of b^2 for axis-aligned packets (rounding is monotone),
 //     cone + four side planes for packets from one origin, interval arithmetic otherwise;
@@ -1322,10 +1322,9 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             reinterpret_cast<const int4*>(a.nodes), a.leaves, int(n_nodes), node_prims);
         GRACE_CHECK_LAUNCH();
         a.node_prims = node_prims;
-        // Wider sweeps pay off once every SIMD holds several packets; with few packets the walk
-        // is latency-bound and shorter sweeps win (measured: 10^7 spheres / 1024^2 rays vs
-        // 10^6 spheres / 10^5 rays).
-        const int auto_treelet = ceil_div(n_rays, 64) >= 4096 ? 512 : 256;
+        // Subtrees of up to 512 primitives are swept rather than descended (measured best or
+        // within 4 % of best on all five BASELINE configurations and on 1/8 ... 1/2 image shards).
+        const int auto_treelet = 512;
 #ifdef GRACE_PACKET_STATS
         a.treelet = g_treelet < 0 ? auto_treelet : g_treelet;
 #else

@@ -230,8 +230,7 @@ grace_status grace_trace_set_packet_width(int rays_per_packet);
 grace_status grace_trace_set_exact_integrals(int enabled);
 
 /* Subtrees with at most this many primitives are swept in one culling pass instead of being
- * descended (results per ray unchanged).  0 disables; -1 (default) picks 512 when the call
- * has >= 4096 packets of 64 rays, else 256. */
+ * descended (results per ray unchanged).  0 disables; -1 (default) = 512. */
 grace_status grace_trace_set_treelet_size(int max_primitives);
 
 /* Reads (and clears) the traversal status word: GRACE_STACK_OVERFLOW if any packet ran out
