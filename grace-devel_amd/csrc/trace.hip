@@ -55,7 +55,8 @@
 //     tree, and, because classes interleave along the Morton order, an even share of the
 //     work for any beam -- with NO change of the result: each wave reduces its classes, a
 //     tiny kernel finishes the tree.  K is the smallest power of two that puts >= 16384 waves
-//     in flight.  A wave keeps its class accumulators in LDS (2 KiB) and switches at granule
+//     in flight; for batches of one direction (light packets) a device-side choice lowers it
+//     to what reaches 4096 waves (choose_split_kernel).  A wave keeps its class accumulators in LDS (2 KiB) and switches at granule
 //     boundaries, once per culling round at most.  Hit counts split the same way (integers);
 //   * per-hit outputs (ordered per ray): large batches stage hits per lane in LDS and drain
 //     them eight entries per ray; small batches split a packet over K waves by contiguous
@@ -115,6 +116,9 @@ struct TraceArgs {
     int split;              // waves per packet (1, 2, 4, 8); each owns SUM_CLASSES / split classes
     int n_prims;
     float* partial;         // split > 1, cumulative: [n_rays][split] subtree sums
+    // Class split only: the number of waves per packet that actually work (a power of two <=
+    // split, chosen on the device from the batch's coherence); waves beyond it exit at once.
+    const int* split_dev;
     // Split per-hit trace (small batches): primitives are cut into n_chunks ranges of
     // 2^chunk_shift consecutive indices.  The counting pass fills chunk_counts[ray][chunk];
     // the per-hit pass lets wave (packet, part) own chunks part_bounds[packet][part ..
@@ -594,6 +598,25 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     // (plane base + 8 j) serves all of a survivor's reads through immediate offsets.
     // (66 slots: the survivor loop reads up to two slots past the round's last survivor)
     __shared__ float2 s_tile[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 3 : 1][LDS_TILE ? 66 : 1];
+    const int lane = threadIdx.x & 63;
+    constexpr bool SPLITTABLE = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
+    static_assert(!SPLIT || SPLITTABLE, "triangle and stats walks do not split");
+    // Hit counts and column densities split a packet by summation class (interleaved granules);
+    // the per-hit trace, whose output is ordered, by contiguous chunk ranges chosen per packet.
+    constexpr bool RANGE_SPLIT = SPLIT && MODE == MODE_HITS;
+    // Waves per packet: as launched, or fewer when the device-side choice (choose_split_kernel)
+    // says so.  The working waves are packed into the first workgroups -- surplus workgroups exit
+    // whole, before touching LDS, so that they do not hold resources of the working ones.
+    const int split = !SPLIT ? 1 : (!RANGE_SPLIT && a.split_dev) ? *a.split_dev : a.split;
+    const int n_packets = (a.n_rays + a.width - 1) / a.width;
+    const int nb = (n_packets * split + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64);   // working workgroups
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only, never
+    // correctness): give each XCD a contiguous run of packets.
+    const int q = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (slot >= q + (xcd < r8 ? 1 : 0)) return;
+    const int vblock = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
+    const int wave_id = __builtin_amdgcn_readfirstlane(vblock * (TRACE_BLOCK / 64)
+                                                       + (threadIdx.x >> 6));
     if (MODE == MODE_CUMULATIVE || MODE == MODE_HITS) {
         if (threadIdx.x < N_TABLE + (FAST ? 1 : 0)) {
             const int i0 = threadIdx.x < N_TABLE ? threadIdx.x : N_TABLE - 1;
@@ -604,20 +627,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
         }
         __syncthreads();
     }
-
-    const int lane = threadIdx.x & 63;
-    // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only, never
-    // correctness): give each XCD a contiguous run of packets.
-    const int nb = gridDim.x, q = nb >> 3, r8 = nb & 7, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int vblock = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
-    const int wave_id = __builtin_amdgcn_readfirstlane(vblock * (TRACE_BLOCK / 64)
-                                                       + (threadIdx.x >> 6));
-    constexpr bool SPLITTABLE = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
-    static_assert(!SPLIT || SPLITTABLE, "triangle and stats walks do not split");
-    // Hit counts and column densities split a packet by summation class (interleaved granules);
-    // the per-hit trace, whose output is ordered, by contiguous chunk ranges chosen per packet.
-    constexpr bool RANGE_SPLIT = SPLIT && MODE == MODE_HITS;
-    const int split = SPLIT ? a.split : 1;
     const int packet = wave_id / split, part = wave_id - packet * split;
     const int first_ray = packet * a.width;
     if (first_ray >= a.n_rays) return;
@@ -1208,10 +1217,12 @@ grace_status ensure_status(hipStream_t stream)
 // Upper levels of the pairwise summation tree for split packets: K subtree sums per ray.
 __global__ __launch_bounds__(256) void combine_classes_kernel(const float* __restrict__ partial,
                                                               int n_rays, int split,
+                                                              const int* __restrict__ split_dev,
                                                               float* __restrict__ out)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
+    if (split_dev) split = *split_dev;
     float t[SUM_CLASSES];
     for (int k = 0; k < split; ++k) t[k] = partial[size_t(r) * split + k];
     for (int w = 1; w < split; w *= 2)
@@ -1266,6 +1277,24 @@ __global__ __launch_bounds__(64) void hits_plan_kernel(const int* __restrict__ c
     }
 }
 
+// How many of the launched waves per packet should work.  The host sizes the launch for an
+// incoherent batch (whose packets are heavy: >= 16384 waves in flight pay off); a batch whose
+// rays all share one direction (orthographic shards) has light packets, for which every extra
+// wave mostly repeats the upper-tree walk: 4096 waves are enough there (measured on 1/8 ... 1/2
+// shards of the 1024^2 image: 1.35 instead of 1.61 ms for 2048 packets).  ext12 = the ray
+// extents of the coherence pass (order-preserving uints: minima then maxima of d, o).
+__global__ void choose_split_kernel(const uint32_t* __restrict__ ext12, int n_packets, int launched,
+                                    int* __restrict__ split_dev)
+{
+    const bool one_direction = ext12[0] == ext12[6] && ext12[1] == ext12[7] && ext12[2] == ext12[8];
+    int k = launched;
+    if (one_direction) {
+        k = 1;
+        while (k < launched && n_packets * k < 4096) k *= 2;
+    }
+    *split_dev = k;
+}
+
 int g_split = -1; // waves per packet; -1: automatic
 int g_width = -1; // rays per packet of the per-hit / triangle traces; -1: automatic
 bool g_exact_integrals = false; // column-density trace: bit-reproducible per-hit arithmetic
@@ -1293,6 +1322,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     const bool hits_split = hit_split > 1;
     int* chunk_counts = nullptr; int* chunk_off = nullptr; int* part_bounds = nullptr;
     int* scratch_counts = nullptr;
+    uint32_t* ray_ext = nullptr;
     {
         constexpr bool need_b = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
         const bool reorder = g_ray_reorder && n_rays > 64;
@@ -1331,7 +1361,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         a.treelet = (MODE == MODE_STATS) ? 0 : (g_treelet < 0 ? auto_treelet : g_treelet);
 #endif
         if (reorder) {
-            uint32_t* ext = Workspace::take<uint32_t>(12);
+            uint32_t* ext = Workspace::take<uint32_t>(16);   // 12 extents + the device-side split
             uint32_t* keys = Workspace::take<uint32_t>(n_rays);
             uint32_t* perm = Workspace::take<uint32_t>(n_rays);
             GRACE_TRY_HIP(hipMemsetAsync(ext, 0xFF, 24, stream));
@@ -1344,6 +1374,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             GRACE_CHECK_LAUNCH();
             GRACE_TRY(sort_pairs_u32_nested(keys, nullptr, n_rays, 0, 0, 30, perm, stream));
             a.perm = perm;
+            ray_ext = ext;
         }
         if (MODE == MODE_TRI)
             tri_prepass_kernel<<<stream_grid(n_spheres + 4, 256), 256, 0, stream>>>(
@@ -1376,6 +1407,13 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     }
     if (hits_split) split = hit_split;
     a.split = split;
+    a.split_dev = nullptr;
+    if ((MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) && split > 1 && g_split <= 0 && ray_ext) {
+        int* split_dev = reinterpret_cast<int*>(ray_ext + 12);
+        choose_split_kernel<<<1, 1, 0, stream>>>(ray_ext, n_packets, split, split_dev);
+        GRACE_CHECK_LAUNCH();
+        a.split_dev = split_dev;
+    }
     a.n_prims = int(n_spheres);
     a.chunk_shift = hit_chunk_shift;
     a.n_chunks = hit_chunks;
@@ -1431,7 +1469,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     GRACE_CHECK_LAUNCH();
     if (MODE == MODE_CUMULATIVE && split > 1) {
         combine_classes_kernel<<<ceil_div(n_rays, 256), 256, 0, stream>>>(a.partial, int(n_rays),
-                                                                          split, a.out_sums);
+                                                                          split, a.split_dev, a.out_sums);
         GRACE_CHECK_LAUNCH();
     }
     if (g_timing) {
