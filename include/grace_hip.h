@@ -211,7 +211,8 @@ grace_status grace_trace_last_kernel_ms(float* h_ms);
 
 /* Waves per 64-ray packet for the hit-count and cumulative traces: 1, 2, 4 or 8 (each wave
  * owns 8/K of the 8 interleaved primitive classes over which the column density is summed), or
- * -1 (default) = as many as it takes to put >= 16384 waves on the chip.  The results do not
+ * -1 (default) = as many as it takes to put >= 16384 waves on the chip (>= 4096 if all rays of
+ * the batch share one direction: decided on the device from the ray extents).  The results do not
  * depend on it (see csrc/trace.hip, "class-ordered sums and packet splitting"). */
 grace_status grace_trace_set_packet_split(int waves_per_packet);
 
