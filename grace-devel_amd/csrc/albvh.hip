@@ -373,6 +373,8 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
                   "max_per_leaf must be less than the total number of primitives.");
     GRACE_REQUIRE(n < (size_t(1) << 31), "build_ALBVH: at most 2^31 - 1 primitives");
     const int ni = int(n);
+    GRACE_TRY(scene_invalidate_if_written(d_nodes));   // a prepared trace scene over this tree is stale
+    GRACE_TRY(scene_invalidate_if_written(d_leaves));
 
     const size_t ws = 3 * Workspace::aligned(n * 4) + Workspace::aligned(scan_ws_count(n) * 4)
         + Workspace::aligned((n + 1) * sizeof(D)) + Workspace::aligned(n * 4)

@@ -97,4 +97,7 @@ grace_status sort_pairs_u64_nested(uint64_t* d_keys, void* d_values, size_t n, i
                                    int begin_bit, int end_bit, uint32_t* d_perm,
                                    hipStream_t stream);
 
+// Drops the prepared trace scene (grace_trace_prepare_*) if it was built over d_written.
+grace_status scene_invalidate_if_written(const void* d_written);
+
 } // namespace grace_hip

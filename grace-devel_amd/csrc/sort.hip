@@ -218,6 +218,7 @@ grace_status sort_pairs(Key* d_keys, void* d_values, size_t n, int value_bytes, 
                   "sort: bad bit range");
     GRACE_REQUIRE(!d_values || (value_bytes > 0 && value_bytes % 4 == 0),
                   "sort: value_bytes must be a positive multiple of 4");
+    if (d_values) GRACE_TRY(scene_invalidate_if_written(d_values)); // prepared trace scene: stale
     if (n <= 1) {
         if (n == 1 && d_perm_out) GRACE_TRY_HIP(hipMemsetAsync(d_perm_out, 0, 4, stream));
         return GRACE_OK;

@@ -112,6 +112,8 @@ struct TraceArgs {
     int treelet;            // nodes with <= treelet primitives are swept as one leaf (0: off)
     const float4* A;        // pre-pass: {x, y, z, h*h}, padded by 4 entries
     const float2* B;        // pre-pass: {1/h, (1/h)^2}, padded by 4 entries
+    const float4* C;        // pre-pass: per CLUSTER (64 consecutive primitives) {lo.xyz, -}, {hi.xyz, -}:
+                            // the box of the member spheres, slightly inflated (cluster_boxes_kernel)
     const double* T64;      // MODE_TRI pre-pass: {v, e1, e2} widened to fp64, 9 per triangle
     int split;              // waves per packet (1, 2, 4, 8); each owns SUM_CLASSES / split classes
     int n_prims;
@@ -253,10 +255,58 @@ __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __rest
             if (B) {
                 const float ir = 1.f / s.w;            // functors/trace.cuh:181
                 b = make_float2(ir * b_scale, ir * ir); // functors/trace.cuh:184 (b_scale 1, or 50: fast)
+                // The fast integral's branch-free rounds add (table value 0) * (1/h^2) for a
+                // candidate the ray misses: keep that product 0 when 1/h^2 overflows (h < 5e-20).
+                if (b_scale != 1.0f) b.y = fminf(b.y, 3.4028234664e38f);
             }
         }
         A[i] = a;
         if (B) B[i] = b;
+    }
+}
+
+// ---- cluster boxes ---------------------------------------------------------------------------
+// Primitives are Morton-sorted, so 64 consecutive ones (a CLUSTER: indices [64 c, 64 c + 64)) are
+// a compact clump about as wide as a smoothing length.  One box per cluster -- the union of
+// the member spheres' boxes [c - h, c + h] -- lets a sweep drop 64 candidates with one lane's
+// test instead of 64 lanes' tests: a swept subtree first tests its clusters (lane j <-> cluster
+// j), then runs culling rounds only over the clusters that survive.  Never a result: a cluster
+// is dropped only if no ray of the packet can hit any member, so per-ray hit sets are unchanged.
+// The half-width is inflated by 4 ulp of the co-ordinate magnitude: sphere_hit's own rounding
+// (q = fl(s - o), b2 = fl(fl(q1^2) + fl(q2^2)) < h^2 admits |s - o| up to h (1 + 3 u) + u |s|).
+// A = {x, y, z, r^2} as written by the pre-passes (spheres: r = h; triangles: bounding radius).
+__global__ __launch_bounds__(256) void cluster_boxes_kernel(const float4* __restrict__ A, size_t n,
+                                                            float4* __restrict__ C)
+{
+    const size_t n_clusters = (n + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    for (size_t c = blockIdx.x * size_t(blockDim.x / 64) + (threadIdx.x >> 6); c < n_clusters;
+         c += size_t(gridDim.x) * (blockDim.x / 64)) {
+        const size_t i = c * 64 + lane;
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        if (i < n) {
+            const float4 s = A[i];
+            const float r = sqrtf(s.w) * 1.00001f;   // sqrt(fl(h h)) can round below h
+            const float ctr[3] = { s.x, s.y, s.z };
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float slack = (fabsf(ctr[k]) + r) * 4.76837158203125e-07f; // 2^-21
+                lo[k] = (ctr[k] - r) - slack;
+                hi[k] = (ctr[k] + r) + slack;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+            }
+        }
+        if (lane == 0) {
+            C[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
+            C[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
     }
 }
 
@@ -457,7 +507,7 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
             for (int k = 5; k >= 0; --k) // origin x is the least significant dimension
                 if (scale[k] > 0.f) key = (key << 1) | ((q[k] >> b) & 1u);
         }
-        keys[i] = key;
+        keys[i] = key << (30 - bits * nvar);   // left-aligned in 30 bits (the host sorts the top bits)
     }
 }
 
@@ -510,7 +560,8 @@ __device__ __forceinline__ float wave_max(float v)
 // sphere_hit's computed b2 differs from the true value by < ~16 u |p|^2 (u = 2^-24; |b| <= |p|)
 // and the interval end points carry similar rounding; the margin 2^-18 |p|^2_hi covers both
 // with a factor > 16 to spare.  Any NaN keeps the sphere.
-__device__ __forceinline__ bool beam_may_hit(const float4 s, const Beam& bm)
+__device__ __forceinline__ bool beam_may_hit(const float4 s, const Beam& bm,
+                                             const float margin = 3.814697265625e-06f /* 2^-18 */)
 {
     float p2_lo = 0.f, p2_hi = 0.f, t_lo = 0.f, t_hi = 0.f;
     const float c[3] = { s.x, s.y, s.z };
@@ -526,7 +577,7 @@ __device__ __forceinline__ bool beam_may_hit(const float4 s, const Beam& bm)
         t_hi += fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
     }
     const float t2_hi = fmaxf(t_lo * t_lo, t_hi * t_hi);
-    const float b2_lo = p2_lo - t2_hi - 3.814697265625e-06f * p2_hi; // 2^-18
+    const float b2_lo = p2_lo - t2_hi - margin * p2_hi;
     return !(b2_lo >= s.w);
 }
 
@@ -580,6 +631,38 @@ __device__ __forceinline__ bool axis_beam_may_hit(const float4 s, const Beam& bm
     const float q2 = s2 - __builtin_amdgcn_fmed3f(s2, bm.olo[D2], bm.ohi[D2]);
     const float b2_lo = q1 * q1 + q2 * q2;
     return !(b2_lo >= s.w);
+}
+
+// Cluster tests (see cluster_boxes_kernel): may any ray of the packet hit any member of the
+// cluster with box [blo, bhi]?  Axis-aligned packets: the box against the packet's origin
+// rectangle in the two perpendicular components (a member is hit only by a ray whose origin
+// lies inside the member's own inflated box, which the cluster box contains).  Other packets: the
+// box's circumscribed sphere through the same conservative tests as a single candidate, with a
+// wider margin (a hit member at distance < h (1 + e) of a ray puts the centre of the cluster
+// within |c - C| + h (1 + e) <= R (1 + e) of it).  Any NaN keeps the cluster.
+__device__ __forceinline__ float4 cluster_sphere(const float4 blo, const float4 bhi)
+{
+    const float cx = 0.5f * (blo.x + bhi.x), cy = 0.5f * (blo.y + bhi.y), cz = 0.5f * (blo.z + bhi.z);
+    const float ex = bhi.x - cx, ey = bhi.y - cy, ez = bhi.z - cz;
+    const float fx = cx - blo.x, fy = cy - blo.y, fz = cz - blo.z;
+    const float rx = fmaxf(ex, fx), ry = fmaxf(ey, fy), rz = fmaxf(ez, fz);
+    return make_float4(cx, cy, cz, (rx * rx + ry * ry + rz * rz) * 1.001f);
+}
+
+template <int AX>
+__device__ __forceinline__ bool cluster_may_hit(const float4 blo, const float4 bhi, const Beam& bm,
+                                                const Pencil* pc)
+{
+    if constexpr (AX >= 0) {
+        constexpr int D1 = AX == 0 ? 1 : 0, D2 = AX == 2 ? 1 : 2;
+        const float lo1 = AX == 0 ? blo.y : blo.x, hi1 = AX == 0 ? bhi.y : bhi.x;
+        const float lo2 = AX == 2 ? blo.y : blo.z, hi2 = AX == 2 ? bhi.y : bhi.z;
+        return !(lo1 > bm.ohi[D1]) && !(hi1 < bm.olo[D1]) && !(lo2 > bm.ohi[D2]) && !(hi2 < bm.olo[D2]);
+    } else if constexpr (AX == -2) {
+        return pencil_may_hit(cluster_sphere(blo, bhi), *pc);
+    } else {
+        return beam_may_hit(cluster_sphere(blo, bhi), bm, 1.52587890625e-05f /* 2^-16 */);
+    }
 }
 
 // ALT selects the mode's alternative code path: the fast kernel integral of the column-density
@@ -939,35 +1022,68 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             // component selection of the axis path is resolved at compile time.
             auto sweep_range = [&](auto ax_tag) {
                 constexpr int AX = decltype(ax_tag)::value;
-            const float4* pa = a.A + leaf.x;
-            const float2* pb = a.B + leaf.x;
             constexpr bool NEED_B = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
-            // The round's 64 candidates are fetched one round ahead (vector loads, 16 B/lane,
-            // coalesced) so that their latency hides behind the previous round's survivors.
-            float4 mine_next = pa[lane < leaf.y ? lane : 0];
-            float2 mineb_next = make_float2(0.f, 0.f);
-            if (LDS_TILE && NEED_B) mineb_next = pb[lane < leaf.y ? lane : 0];
-            for (int base = 0; base < leaf.y; base += 64) {
-                const int m = min(64, leaf.y - base);
-                // Lane j: can ANY ray of the beam come within h of sphere j?
-                const float4 mine = mine_next;
-                const float2 mineb = mineb_next;
-                if (base + 64 < leaf.y) {
-                    const int nj = base + 64 + lane;
-                    mine_next = pa[nj < leaf.y ? nj : base + 64];
-                    if (LDS_TILE && NEED_B) mineb_next = pb[nj < leaf.y ? nj : base + 64];
+            const int wv = threadIdx.x >> 6;
+            const int r_lo = leaf.x, r_hi = leaf.x + leaf.y;   // the swept primitives (wave-uniform)
+            const int c_first = r_lo >> 6, c_last = (r_hi - 1) >> 6;
+            // Lane j's candidate of cluster c: primitive 64 c + j, clamped into the range (idle
+            // lanes then hold a valid candidate and the tests need no control flow).
+            auto load_cluster = [&](const int c, float4& m4, float2& m2) {
+                const int pj = min(max((c << 6) + lane, r_lo), r_hi - 1);
+                m4 = a.A[pj];
+                if (LDS_TILE && NEED_B) m2 = a.B[pj];
+            };
+            // The range's clusters, 64 at a time: lane j decides for cluster cg + j whether ANY ray
+            // of the packet can hit ANY of its members (cluster_may_hit); culling rounds then run
+            // over the surviving clusters only, in ascending order.
+            for (int cg = c_first; cg <= c_last; cg += 64) {
+                unsigned long long cmask = 1ull;
+                if (c_last != c_first) {   // (one cluster -- a small leaf -- goes straight to its round)
+                    const int cj = min(cg + lane, c_last);
+                    const float4 blo = a.C[2 * size_t(cj)], bhi = a.C[2 * size_t(cj) + 1];
+                    const bool c_may = cluster_may_hit<AX>(blo, bhi, beam, &s_pencil[wv]);
+                    const int n_c = min(64, c_last - cg + 1);
+                    cmask = __builtin_amdgcn_ballot_w64(c_may)
+                        & (n_c >= 64 ? ~0ull : ((1ull << n_c) - 1ull));
+                    // A wave of a split packet sweeps its own clusters only (a cluster lies inside
+                    // one granule: 1024 = 16 x 64).
+                    if (SPLIT) cmask &= __builtin_amdgcn_ballot_w64(owns_granule(cj >> (GRANULE_SHIFT - 6)));
+#ifdef GRACE_PACKET_STATS
+                    if (MODE == MODE_STATS) st_leaves += 1;
+#endif
                 }
+                if (cmask == 0ull) continue;
+                int cnext = cg + __builtin_ctzll(cmask);
+                cmask &= cmask - 1ull;
+                // A round's 64 candidates are fetched one round ahead (vector loads, 16 B/lane,
+                // coalesced) so that their latency hides behind the previous round's survivors.
+                float4 mine_next;
+                float2 mineb_next = make_float2(0.f, 0.f);
+                load_cluster(cnext, mine_next, mineb_next);
+                for (;;) {
+                    const int pbase = cnext << 6;          // first primitive of this round's cluster
+                    const float4 mine = mine_next;
+                    const float2 mineb = mineb_next;
+                    const bool more = cmask != 0ull;
+                    if (more) {
+                        cnext = cg + __builtin_ctzll(cmask);
+                        cmask &= cmask - 1ull;
+                        load_cluster(cnext, mine_next, mineb_next);
+                    }
+                    const int lo_bit = max(r_lo - pbase, 0), hi_bit = min(r_hi - pbase, 64);
+                    const unsigned long long m_mask =
+                        (hi_bit >= 64 ? ~0ull : ((1ull << hi_bit) - 1ull)) & (~0ull << lo_bit);
+                // Lane j: can ANY ray of the beam come within h of sphere j?
                 // (The tests run on every lane -- idle lanes hold a clamped, valid candidate -- so
                 // there is no control flow; lane masks are formed from ballots of the bare
                 // comparisons and combined on the scalar unit: a ballot of a combined boolean
                 // costs two extra vector instructions each.)
                 bool may_hit;
                 if constexpr (AX >= 0) may_hit = axis_beam_may_hit<AX>(mine, beam);
-                else if constexpr (AX == -2) may_hit = pencil_may_hit(mine, s_pencil[threadIdx.x >> 6]);
+                else if constexpr (AX == -2) may_hit = pencil_may_hit(mine, s_pencil[wv]);
                 else may_hit = beam_may_hit(mine, beam);
-                const unsigned long long m_mask = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
                 unsigned long long rest = __builtin_amdgcn_ballot_w64(may_hit) & m_mask;
-                const bool keep = may_hit & (lane < m);
+                const bool keep = may_hit & (lane >= lo_bit) & (lane < hi_bit);
                 // Axis packets: if every kept candidate lies inside every ray's [0, length)
                 // along the axis -- decided per candidate with the same FMA the rays use, which
                 // is monotone in its addend -- the round's survivors skip the two range tests.
@@ -980,15 +1096,26 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     lean_round = same_sense & ((rest & ~inside) == 0ull);
                 }
 #ifdef GRACE_PACKET_STATS
-                if (MODE == MODE_STATS) { st_leaves += 1; st_tested += __builtin_popcountll(rest); }
+                if (MODE == MODE_STATS) { st_tested += __builtin_popcountll(rest); }
 #endif
-                if (rest == 0ull) continue;
-                const int wv = threadIdx.x >> 6;
                 // Hit counts and column densities need no candidate index: their tile holds the
                 // survivors only, in ascending order (slot = number of kept lanes below), so the
                 // k-th survivor sits at slot k -- no bit scanning, and slot addresses that differ
                 // by immediates.  The per-hit and triangle modes keep lane-indexed tiles.
                 constexpr bool COMPACT = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE);
+                // The round's survivors belong to ONE granule (a cluster never straddles two), so
+                // the class accumulator switch and the ownership test of a split packet stay out
+                // of the per-survivor loop.
+                bool skip_round = rest == 0ull;
+                if (!skip_round && (CLASSES || SPLIT)) {
+                    const int pf = pbase + __builtin_ctzll(rest);
+                    if (CLASSES && pf >= cur_granule_end) enter_granule(pf); // ascending index
+                    if (SPLIT && !(CLASSES ? cur_owned : owns_granule(pf >> GRANULE_SHIFT)))
+                        skip_round = true;
+                    else if (CHUNKED && (MODE == MODE_HITS || a.chunk_counts) && (pf >> a.chunk_shift) != cur_chunk)
+                        enter_chunk(pf >> a.chunk_shift);
+                }
+                if (!skip_round) {
                 if (LDS_TILE) {
                     // Stage the round's candidates; survivors are then broadcast-read from LDS
                     // into VGPRs (in-order LDS returns, no scalar-load round trips, VGPR operands).
@@ -1002,41 +1129,18 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         if (NEED_B) s_tile[wv][LDS_TILE ? 2 : 0][slot] = mineb;
                     }
                 }
-                int next_slot = 0; // COMPACT: survivors of this round consumed so far
-                // The round's survivors are taken granule by granule (a round of 64 consecutive
-                // primitives touches at most two), so that the class accumulator switch and the
-                // ownership test of a split packet stay out of the per-survivor loop.
-#pragma nounroll
-                while (rest != 0ull) {
-                unsigned long long todo = rest;
-                rest = 0ull;
-                if (CLASSES || SPLIT) {
-                    const int p0 = leaf.x + base;
-                    const int pf = p0 + __builtin_ctzll(todo);
-                    const int cut = (((pf >> GRANULE_SHIFT) + 1) << GRANULE_SHIFT) - p0;
-                    if (cut < 64) {
-                        const unsigned long long below = (1ull << cut) - 1ull;
-                        rest = todo & ~below;
-                        todo &= below;
-                    }
-                    if (CLASSES && pf >= cur_granule_end) enter_granule(pf); // ascending index
-                    if (SPLIT && !(CLASSES ? cur_owned : owns_granule(pf >> GRANULE_SHIFT))) {
-                        next_slot += __builtin_popcountll(todo);
-                        continue;
-                    }
-                    if (CHUNKED && (MODE == MODE_HITS || a.chunk_counts) && (pf >> a.chunk_shift) != cur_chunk)
-                        enter_chunk(pf >> a.chunk_shift);
-                }
-                // One survivor: the packet's 64 rays against candidate jj (wave-uniform).
+                const unsigned long long todo = rest;
+                // One survivor: the packet's 64 rays against candidate jj (wave-uniform primitive
+                // index; 0 for the compacted tiles, which do not need it).
                 auto process = [&](auto lean_tag, const float4 s, const float2 sb, const int jj) {
                     constexpr bool LEAN = decltype(lean_tag)::value;
                     if (MODE == MODE_TRI) {
                         // RayIntersect_tri + OnHit_tri (tris_trace.cuh:24-61)
                         float t;
-                        if (tri_intersect(ddx, ddy, ddz, ox, oy, oz, a.T64 + 9 * size_t(leaf.x + jj), &t)) {
+                        if (tri_intersect(ddx, ddy, ddz, ox, oy, oz, a.T64 + 9 * size_t(jj), &t)) {
                             if (t <= tri_tmin && t >= 1E-14f) {
                                 tri_tmin = t;
-                                tri_data = leaf.x + jj;
+                                tri_data = jj;
                             }
                         }
                     } else {
@@ -1058,6 +1162,19 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                             const float bz = pz - dot_p * dz;
                             b2 = bx * bx + by * by + bz * bz;
                         }
+                        if constexpr (FAST && LEAN) {
+                            // No hit test at all: a candidate the ray misses has b2 >= h^2, hence a
+                            // table position >= 50 (the product of the two rounded factors is monotone),
+                            // which clamps to the table's last entry (y = 0, dy = 0): it adds exactly
+                            // +0.  Same bits as the tested path, without the compare, the EXEC
+                            // round trip and the branch.
+                            const float b = fminf(__builtin_amdgcn_sqrtf(b2) * sb.x, float(N_TABLE - 1));
+                            const int x_idx = static_cast<int>(b);
+                            const float t = __builtin_amdgcn_fractf(b);
+                            const float2 y = s_lutf[x_idx];
+                            sum = __builtin_fmaf(__builtin_fmaf(t, y.y, y.x), sb.y, sum);
+                            return;
+                        }
                         const bool hit = LEAN ? !(b2 >= s.w)
                                               : !(b2 >= s.w) && !(dot_p < 0.0f) && !(dot_p >= len);
 #ifdef GRACE_PACKET_STATS
@@ -1073,13 +1190,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                             } else if (MODE == MODE_CUMULATIVE) {
                                 sum += w;
                             } else if (valid && !STAGE_HITS) {
-                                a.hit_idx[write_at] = leaf.x + jj;
+                                a.hit_idx[write_at] = jj;
                                 a.hit_integral[write_at] = w;
                                 a.hit_dist[write_at] = dot_p;
                                 ++write_at;
                             } else if (valid) {
                                 const int wvh = threadIdx.x >> 6;
-                                s_hits[wvh][0][staged][lane] = __int_as_float(leaf.x + jj);
+                                s_hits[wvh][0][staged][lane] = __int_as_float(jj);
                                 s_hits[wvh][STAGE_HITS ? 1 : 0][staged][lane] = w;
                                 s_hits[wvh][STAGE_HITS ? 2 : 0][staged][lane] = dot_p;
                                 ++staged;
@@ -1103,7 +1220,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     } else {
                         at = __builtin_ctzll(td);
                         td = (td & ~(1ull << at)) | 0x8000000000000000ull;
-                        jj = base + at;
+                        jj = min(pbase + at, r_hi - 1);
                     }
                     if (LDS_TILE) {
                         const float2 xy = s_tile[wv][0][at];
@@ -1114,7 +1231,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                         // letting the scheduler sink them next to their use.
                         __builtin_amdgcn_sched_barrier(0);
                     } else {
-                        c = pa[jj];
+                        c = a.A[jj];
                     }
                 };
                 auto run = [&](auto lean_tag) {
@@ -1125,8 +1242,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                     int j0, j1 = 0, j2 = 0;
                     int left = __builtin_popcountll(todo);
                     unsigned long long td = todo | 0x8000000000000000ull;
-                    int k = next_slot;
-                    next_slot += left;
+                    int k = 0;
                     fetch(td, k, c0, b0, j0);
                     fetch(td, k, c1, b1, j1);
                     for (;;) {
@@ -1143,7 +1259,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
                 };
                 if (lean_round) run(std::true_type());
                 else run(std::false_type());
-                } // granule chunks of the round
+                } // !skip_round
+                    if (!more) break;
+                } // rounds over the surviving clusters
             }
             };
             switch (axis) {
@@ -1299,14 +1417,102 @@ int g_split = -1; // waves per packet; -1: automatic
 int g_width = -1; // rays per packet of the per-hit / triangle traces; -1: automatic
 bool g_exact_integrals = false; // column-density trace: bit-reproducible per-hit arithmetic
 
+// ---- scene-constant pre-pass data --------------------------------------------------------
+// A, B, the nodes' primitive spans and the cluster boxes depend on the primitives and the tree
+// only.  By default every trace call recomputes them into the workspace (the reference's
+// trace calls are stateless too); grace_trace_prepare_f4 / _tri computes them ONCE into buffers
+// of their own, and later trace calls whose primitive / node / leaf pointers and sizes match
+// reuse them (0.25 ms per call at 10^7 particles -- a fifth of a 1/8-image shard's trace).  The
+// caller promises not to change those arrays until grace_trace_release(); this library's own
+// sort and build entry points drop the cache when they write to one of them.
+struct Scene {
+    bool valid = false, tri = false;
+    const void* prims = nullptr; const void* nodes = nullptr; const void* leaves = nullptr;
+    size_t n_prims = 0, n_nodes = 0;
+    float4* A = nullptr; float2* B1 = nullptr; float2* B50 = nullptr; double* T64 = nullptr;
+    int2* node_prims = nullptr; float4* C = nullptr;
+};
+Scene g_scene;
+
+grace_status scene_release()
+{
+    if (g_scene.A || g_scene.B1 || g_scene.B50 || g_scene.T64 || g_scene.node_prims || g_scene.C)
+        GRACE_TRY_HIP(hipDeviceSynchronize());
+    void* bufs[] = { g_scene.A, g_scene.B1, g_scene.B50, g_scene.T64, g_scene.node_prims, g_scene.C };
+    for (void* b : bufs)
+        if (b) GRACE_TRY_HIP(hipFree(b));
+    g_scene = Scene();
+    return GRACE_OK;
+}
+
+// Fills the scene-constant arrays (any of B1 / B50 / T64 may be null).
+grace_status scene_fill(bool tri, const void* prims, size_t n_prims, const float4* nodes,
+                        size_t n_nodes, const int4* leaves, float4* A, float2* B1, float2* B50,
+                        double* T64, int2* node_prims, float4* C, hipStream_t stream)
+{
+    node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
+        reinterpret_cast<const int4*>(nodes), leaves, int(n_nodes), node_prims);
+    GRACE_CHECK_LAUNCH();
+    if (tri) {
+        tri_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
+            static_cast<const float*>(prims), n_prims, A, T64);
+        GRACE_CHECK_LAUNCH();
+    } else {
+        trace_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
+            static_cast<const float4*>(prims), n_prims, A, B1 ? B1 : B50,
+            B1 ? 1.0f : float(N_TABLE - 1));
+        GRACE_CHECK_LAUNCH();
+        if (B1 && B50) {
+            trace_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
+                static_cast<const float4*>(prims), n_prims, A, B50, float(N_TABLE - 1));
+            GRACE_CHECK_LAUNCH();
+        }
+    }
+    cluster_boxes_kernel<<<stream_grid((n_prims + 63) / 64, 4), 256, 0, stream>>>(A, n_prims, C);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+grace_status scene_prepare(bool tri, const void* prims, size_t n_prims, const int* d_nodes,
+                           size_t n_nodes, const int* d_leaves, hipStream_t stream)
+{
+    GRACE_REQUIRE(prims && d_nodes && d_leaves, "trace_prepare: null pointer");
+    GRACE_REQUIRE(n_prims > 0 && n_nodes >= 1, "trace_prepare: empty scene");
+    GRACE_TRY(scene_release());
+    Scene sc;
+    auto alloc = [&](void** ptr, size_t bytes) -> grace_status {
+        hipError_t e = hipMalloc(ptr, bytes);
+        if (e != hipSuccess)
+            return set_error(GRACE_OUT_OF_MEMORY, __FILE__, __LINE__, hipGetErrorString(e));
+        return GRACE_OK;
+    };
+    grace_status st = alloc(reinterpret_cast<void**>(&sc.A), (n_prims + 4) * sizeof(float4));
+    if (st == GRACE_OK && !tri) st = alloc(reinterpret_cast<void**>(&sc.B1), (n_prims + 4) * sizeof(float2));
+    if (st == GRACE_OK && !tri) st = alloc(reinterpret_cast<void**>(&sc.B50), (n_prims + 4) * sizeof(float2));
+    if (st == GRACE_OK && tri) st = alloc(reinterpret_cast<void**>(&sc.T64), 72 * (n_prims + 4));
+    if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.node_prims), n_nodes * sizeof(int2));
+    if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.C), 2 * ((n_prims + 63) / 64) * sizeof(float4));
+    g_scene = sc;   // so that a failure below releases what was allocated
+    if (st != GRACE_OK) { scene_release(); return st; }
+    st = scene_fill(tri, prims, n_prims, reinterpret_cast<const float4*>(d_nodes), n_nodes,
+                    reinterpret_cast<const int4*>(d_leaves), sc.A, sc.B1, sc.B50, sc.T64,
+                    sc.node_prims, sc.C, stream);
+    if (st != GRACE_OK) { scene_release(); return st; }
+    g_scene.valid = true; g_scene.tri = tri;
+    g_scene.prims = prims; g_scene.nodes = d_nodes; g_scene.leaves = d_leaves;
+    g_scene.n_prims = n_prims; g_scene.n_nodes = n_nodes;
+    return GRACE_OK;
+}
+
 template <int MODE>
 grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n_nodes,
                           hipStream_t stream)
 {
     GRACE_REQUIRE(a.rays && a.spheres && a.nodes && a.leaves && a.root, "trace: null pointer");
-    GRACE_REQUIRE(n_rays > 0 && n_rays < (size_t(1) << 31), "trace: bad ray count");
+    GRACE_REQUIRE(n_rays < (size_t(1) << 31), "trace: bad ray count");
     GRACE_REQUIRE(n_nodes >= 1 && n_nodes < (size_t(1) << 30), "trace: bad node count");
-    GRACE_REQUIRE(n_spheres > 0, "trace: no primitives");
+    GRACE_REQUIRE(n_spheres > 0 && n_spheres < (size_t(1) << 31), "trace: bad primitive count");
+    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_TRY(ensure_status(stream));
     // Split per-hit trace for small batches (see TraceArgs / hits_plan_kernel): chunk size =
     // a power of two >= one granule giving at most MAX_HIT_CHUNKS chunks.
@@ -1325,21 +1531,40 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     uint32_t* ray_ext = nullptr;
     {
         constexpr bool need_b = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
+        const bool fast_b = MODE == MODE_CUMULATIVE && !g_exact_integrals;
         const bool reorder = g_ray_reorder && n_rays > 64;
-        GRACE_TRY(Workspace::begin(Workspace::aligned((n_spheres + 4) * sizeof(float4))
+        const bool cached = g_scene.valid && g_scene.tri == (MODE == MODE_TRI)
+            && g_scene.prims == static_cast<const void*>(a.spheres) && g_scene.n_prims == n_spheres
+            && g_scene.nodes == static_cast<const void*>(a.nodes) && g_scene.n_nodes == n_nodes
+            && g_scene.leaves == static_cast<const void*>(a.leaves);
+        const size_t n_clusters = (n_spheres + 63) / 64;
+        GRACE_TRY(Workspace::begin((cached ? 0 : Workspace::aligned((n_spheres + 4) * sizeof(float4))
+                                               + Workspace::aligned((n_spheres + 4) * sizeof(float2))
+                                               + Workspace::aligned(n_nodes * sizeof(int2))
+                                               + Workspace::aligned(2 * n_clusters * sizeof(float4))
+                                               + (MODE == MODE_TRI ? Workspace::aligned(72 * (n_spheres + 4)) : 0))
                                    + (hits_split ? 2 * Workspace::aligned(n_rays * size_t(hit_chunks) * 4)
                                                    + Workspace::aligned(hit_packets * (hit_split + 1) * 4)
                                                    + Workspace::aligned(n_rays * 4) : 0)
-                                   + Workspace::aligned((n_spheres + 4) * sizeof(float2))
-                                   + Workspace::aligned(n_nodes * sizeof(int2))
-                                   + (MODE == MODE_TRI ? Workspace::aligned(72 * (n_spheres + 4)) : 0)
                                    + (MODE == MODE_CUMULATIVE ? Workspace::aligned(n_rays * SUM_CLASSES * 4) : 0)
                                    + (reorder ? 2 * Workspace::aligned(n_rays * 4)
                                                 + sort_ws_bytes(n_rays, 4, 0) : 0) + 1024));
-        float4* A = Workspace::take<float4>(n_spheres + 4);
-        float2* B = need_b ? Workspace::take<float2>(n_spheres + 4) : nullptr;
-        double* T64 = (MODE == MODE_TRI) ? Workspace::take<double>(9 * (n_spheres + 4)) : nullptr;
-        a.T64 = T64;
+        if (cached) {
+            a.A = g_scene.A;
+            a.B = need_b ? (fast_b ? g_scene.B50 : g_scene.B1) : nullptr;
+            a.T64 = g_scene.T64;
+            a.node_prims = g_scene.node_prims;
+            a.C = g_scene.C;
+        } else {
+            float4* A = Workspace::take<float4>(n_spheres + 4);
+            float2* B = need_b ? Workspace::take<float2>(n_spheres + 4) : nullptr;
+            double* T64 = (MODE == MODE_TRI) ? Workspace::take<double>(9 * (n_spheres + 4)) : nullptr;
+            int2* node_prims = Workspace::take<int2>(n_nodes);
+            float4* C = Workspace::take<float4>(2 * n_clusters);
+            GRACE_TRY(scene_fill(MODE == MODE_TRI, a.spheres, n_spheres, a.nodes, n_nodes, a.leaves, A,
+                                 fast_b ? nullptr : B, fast_b ? B : nullptr, T64, node_prims, C, stream));
+            a.A = A; a.B = B; a.T64 = T64; a.node_prims = node_prims; a.C = C;
+        }
         a.partial = (MODE == MODE_CUMULATIVE) ? Workspace::take<float>(n_rays * SUM_CLASSES) : nullptr;
         if (hits_split) {
             chunk_counts = Workspace::take<int>(n_rays * size_t(hit_chunks));
@@ -1347,14 +1572,9 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             part_bounds = Workspace::take<int>(hit_packets * (hit_split + 1));
             scratch_counts = Workspace::take<int>(n_rays);
         }
-        int2* node_prims = Workspace::take<int2>(n_nodes);
-        node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
-            reinterpret_cast<const int4*>(a.nodes), a.leaves, int(n_nodes), node_prims);
-        GRACE_CHECK_LAUNCH();
-        a.node_prims = node_prims;
-        // Subtrees of up to 512 primitives are swept rather than descended (measured best or
-        // within 4 % of best on all five BASELINE configurations and on 1/8 ... 1/2 image shards).
-        const int auto_treelet = 512;
+        // Subtrees of up to this many primitives are swept -- cluster tests, then culling rounds
+        // over the surviving clusters -- rather than descended.
+        const int auto_treelet = 4096;
 #ifdef GRACE_PACKET_STATS
         a.treelet = g_treelet < 0 ? auto_treelet : g_treelet;
 #else
@@ -1372,20 +1592,18 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(a.rays, int(n_rays), ext,
                                                                         keys);
             GRACE_CHECK_LAUNCH();
-            GRACE_TRY(sort_pairs_u32_nested(keys, nullptr, n_rays, 0, 0, 30, perm, stream));
+            // Only the key bits that decide which PACKET a ray joins need sorting: the order of
+            // the rays inside a packet is irrelevant (log2(packets) + 2 bits, in whole 8-bit
+            // passes; keys are left-aligned in 30 bits).  The sort is stable, so ties keep the
+            // caller's order.
+            int want_bits = 2;
+            while ((size_t(1) << (want_bits - 2)) < hit_packets && want_bits < 30) ++want_bits;
+            want_bits = ((want_bits + 7) / 8) * 8;
+            const int begin_bit = want_bits >= 30 ? 0 : 30 - want_bits;
+            GRACE_TRY(sort_pairs_u32_nested(keys, nullptr, n_rays, 0, begin_bit, 30, perm, stream));
             a.perm = perm;
             ray_ext = ext;
         }
-        if (MODE == MODE_TRI)
-            tri_prepass_kernel<<<stream_grid(n_spheres + 4, 256), 256, 0, stream>>>(
-                reinterpret_cast<const float*>(a.spheres), n_spheres, A, T64);
-        else
-            trace_prepass_kernel<<<stream_grid(n_spheres + 4, 256), 256, 0, stream>>>(
-                a.spheres, n_spheres, A, B,
-                (MODE == MODE_CUMULATIVE && !g_exact_integrals) ? float(N_TABLE - 1) : 1.0f);
-        GRACE_CHECK_LAUNCH();
-        a.A = A;
-        a.B = B;
     }
     a.n_rays = int(n_rays);
     a.n_nodes = int(n_nodes);
@@ -1480,6 +1698,18 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
 }
 
 } // namespace
+
+namespace grace_hip {
+// Called by this library's entry points that WRITE caller arrays (sort payloads, tree builds):
+// a prepared scene over that array is stale from here on.
+grace_status scene_invalidate_if_written(const void* d_written)
+{
+    if (g_scene.valid && d_written
+        && (d_written == g_scene.prims || d_written == g_scene.nodes || d_written == g_scene.leaves))
+        return scene_release();
+    return GRACE_OK;
+}
+} // namespace grace_hip
 
 extern "C" {
 
@@ -1578,6 +1808,20 @@ grace_status grace_hit_integrals_f32(const float* d_b2, const float* d_h, size_t
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
 }
+
+grace_status grace_trace_prepare_f4(const float* d_spheres, size_t n_spheres, const int* d_nodes,
+                                    size_t n_nodes, const int* d_leaves, grace_stream stream)
+{
+    return scene_prepare(false, d_spheres, n_spheres, d_nodes, n_nodes, d_leaves, as_stream(stream));
+}
+
+grace_status grace_trace_prepare_tri(const float* d_tris, size_t n_tris, const int* d_nodes,
+                                     size_t n_nodes, const int* d_leaves, grace_stream stream)
+{
+    return scene_prepare(true, d_tris, n_tris, d_nodes, n_nodes, d_leaves, as_stream(stream));
+}
+
+grace_status grace_trace_release(void) { return scene_release(); }
 
 grace_status grace_trace_enable_timing(int enabled)
 {

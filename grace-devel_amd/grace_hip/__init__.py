@@ -287,6 +287,26 @@ def trace_status():
     _check(_lib.grace_trace_status(_stream()))
 
 
+def trace_prepare(spheres, tree):
+    """Computes the scene-constant trace data (per-sphere records, node spans, cluster boxes)
+    once; later trace calls over the same spheres / tree reuse it until trace_release().  The
+    caller must not modify spheres or tree in between (this library's own sort / build calls
+    drop it themselves).  Not part of the reference API (its traces are stateless)."""
+    _check(_lib.grace_trace_prepare_f4(_ptr(_spheres(spheres)), C.c_size_t(len(spheres)),
+                                       _ptr(tree.nodes), C.c_size_t(tree.n_nodes),
+                                       _ptr(tree.leaves), _stream()))
+
+
+def trace_prepare_tri(tris, tree):
+    _check(_lib.grace_trace_prepare_tri(_ptr(_tris(tris)), C.c_size_t(len(tris)),
+                                        _ptr(tree.nodes), C.c_size_t(tree.n_nodes),
+                                        _ptr(tree.leaves), _stream()))
+
+
+def trace_release():
+    _check(_lib.grace_trace_release())
+
+
 def trace_hitcounts_sph(rays, spheres, tree, hit_counts):
     """trace_sph.cuh:58-80."""
     _check_rays(rays)

@@ -165,8 +165,9 @@ grace_status grace_trace_closest_tri(const void* d_rays, size_t n_rays, const fl
 /* ---- traversal: grace::trace_hitcounts_sph / trace_cumulative_sph / trace_sph pass 2
  *      (include/grace/cuda/trace_sph.cuh:58-168) over trace_kernel
  *      (include/grace/cuda/kernels/bintree_trace.cuh:52-197).  n_nodes = n_leaves - 1.
- *      Any n_rays >= 1 is accepted here; the header mirror enforces the reference's
- *      n_rays % 32 == 0 (bintree_trace.cuh:231-238). ---------------------------------- */
+ *      Any n_rays is accepted here (0: nothing to do, e.g. the empty shard of a sharded
+ *      batch); the header mirror enforces the reference's n_rays % 32 == 0
+ *      (bintree_trace.cuh:231-238). ----------------------------------------------------- */
 grace_status grace_trace_hitcounts_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
                                       size_t n_spheres, const int* d_nodes, size_t n_nodes,
                                       const int* d_leaves, const int* d_root,
@@ -230,9 +231,26 @@ grace_status grace_trace_set_packet_width(int rays_per_packet);
  * The per-hit outputs (grace_trace_hits_f4, grace_hit_integrals_f32) always use the latter. */
 grace_status grace_trace_set_exact_integrals(int enabled);
 
-/* Subtrees with at most this many primitives are swept in one culling pass instead of being
- * descended (results per ray unchanged).  0 disables; -1 (default) = 512. */
+/* Subtrees with at most this many primitives are swept -- one test per cluster of 64 consecutive
+ * primitives, then culling rounds over the surviving clusters -- instead of being descended
+ * (results per ray unchanged).  0 disables; -1 (default) = 4096. */
 grace_status grace_trace_set_treelet_size(int max_primitives);
+
+/* Scene-constant trace data.  Every trace call derives, from the primitives and the tree alone,
+ * per-sphere records ({x, y, z, h^2}, {1/h, 1/h^2}), every node's primitive span and one box per
+ * cluster of 64 consecutive primitives (see csrc/trace.hip).  By default they are recomputed
+ * into the workspace by every call (the reference's traces are stateless: trace_sph.cuh:58-241
+ * rebuild even the 51-entry table per call).  grace_trace_prepare_f4 / _tri computes them once
+ * into buffers of their own; later trace calls whose d_spheres / n_spheres / d_nodes / n_nodes /
+ * d_leaves match reuse them, with bit-identical results.  One scene at a time; a second prepare
+ * replaces the first.  The caller must not modify those arrays until grace_trace_release();
+ * grace_sort_pairs_* and grace_albvh_build_* drop the prepared scene themselves when they write
+ * to one of its arrays.  Not part of the reference API. */
+grace_status grace_trace_prepare_f4(const float* d_spheres, size_t n_spheres, const int* d_nodes,
+                                    size_t n_nodes, const int* d_leaves, grace_stream stream);
+grace_status grace_trace_prepare_tri(const float* d_tris, size_t n_tris, const int* d_nodes,
+                                     size_t n_nodes, const int* d_leaves, grace_stream stream);
+grace_status grace_trace_release(void);
 
 /* Reads (and clears) the traversal status word: GRACE_STACK_OVERFLOW if any packet ran out
  * of its 128-entry stack since the last check (the reference only asserts this in
