@@ -110,6 +110,7 @@ struct TraceArgs {
     const float4* spheres;
     const int2* node_prims; // pre-pass: per node {first primitive, primitive count}
     int treelet;            // nodes with <= treelet primitives are swept as one leaf (0: off)
+    int treelet_axis;       // the same for axis-aligned packets (whose cluster test is much sharper)
     const float4* A;        // pre-pass: {x, y, z, h*h}, padded by 4 entries
     const float2* B;        // pre-pass: {1/h, (1/h)^2}, padded by 4 entries
     const float4* C;        // pre-pass: per CLUSTER (64 consecutive primitives) {lo.xyz, -}, {hi.xyz, -}:
@@ -667,8 +668,11 @@ __device__ __forceinline__ bool cluster_may_hit(const float4 blo, const float4 b
 
 // ALT selects the mode's alternative code path: the fast kernel integral of the column-density
 // trace, the LDS-staged outputs of the per-hit trace.
+// The class-split instantiations are held to 8 waves per SIMD (<= 64 VGPRs, <= 80 SGPRs: the
+// compiler parks ~28 scalars in VGPR lanes): they exist for small batches, where resident waves
+// are what is scarce (1/8-image shard: K = 4 fits the chip at once, 0.82 -> 0.71 ms).
 template <int MODE, bool SPLIT, bool ALT = false>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
+__global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) void trace_kernel(const TraceArgs a)
 {
     static_assert(!ALT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS, "no alternative path for this mode");
     constexpr bool FAST = ALT && MODE == MODE_CUMULATIVE;
@@ -838,6 +842,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
     }
     const float o1 = axis == 0 ? oy : ox;
     const float o2 = axis == 2 ? oy : oz;
+    const int treelet = axis >= 0 ? a.treelet_axis : a.treelet;
 
     int count = 0;
     // Chunk bookkeeping of the split per-hit trace (see TraceArgs): the counting pass adds each
@@ -974,13 +979,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(const TraceArgs a)
             const float4 Z = np[3];
             int2 span = make_int2(0, 0x7fffffff);
 #ifdef GRACE_PACKET_STATS
-            if (a.treelet > 0) span = a.node_prims[idx];
+            if (treelet > 0) span = a.node_prims[idx];
 #else
-            if (MODE != MODE_STATS && (a.treelet > 0 || SPLIT)) span = a.node_prims[idx];
+            if (MODE != MODE_STATS && (treelet > 0 || SPLIT)) span = a.node_prims[idx];
 #endif
             // A wave of a split packet skips subtrees outside its primitive range.
             if (SPLIT && foreign_range(span.x, span.y)) continue;
-            if (span.y <= a.treelet) {
+            if (span.y <= treelet) {
                 sweep = true; sweep_first = span.x; sweep_count = span.y;
             } else {
             // (A wave-uniform box-overlap test of the packet's bounding box -- twelve compares
@@ -1398,8 +1403,7 @@ __global__ __launch_bounds__(64) void hits_plan_kernel(const int* __restrict__ c
 // How many of the launched waves per packet should work.  The host sizes the launch for an
 // incoherent batch (whose packets are heavy: >= 16384 waves in flight pay off); a batch whose
 // rays all share one direction (orthographic shards) has light packets, for which every extra
-// wave mostly repeats the upper-tree walk: 4096 waves are enough there (measured on 1/8 ... 1/2
-// shards of the 1024^2 image: 1.35 instead of 1.61 ms for 2048 packets).  ext12 = the ray
+// wave repeats the upper-tree walk and the cluster tests.  ext12 = the ray
 // extents of the coherence pass (order-preserving uints: minima then maxima of d, o).
 __global__ void choose_split_kernel(const uint32_t* __restrict__ ext12, int n_packets, int launched,
                                     int* __restrict__ split_dev)
@@ -1407,8 +1411,12 @@ __global__ void choose_split_kernel(const uint32_t* __restrict__ ext12, int n_pa
     const bool one_direction = ext12[0] == ext12[6] && ext12[1] == ext12[7] && ext12[2] == ext12[8];
     int k = launched;
     if (one_direction) {
+        // Measured on 1/8 ... 1/1 shards of the 1024^2 frame (2048 ... 16384 packets): best K =
+        // 4, 2, 2, 1.  The split kernels run 8 waves per SIMD: 8192 waves fill the chip once;
+        // from 6144 packets on a second wave per packet still pays (16384 waves).
         k = 1;
-        while (k < launched && n_packets * k < 4096) k *= 2;
+        while (k < launched && n_packets * k < 8192) k *= 2;
+        if (k < launched && n_packets >= 6144 && n_packets * k < 16384) k *= 2;
     }
     *split_dev = k;
 }
@@ -1574,11 +1582,16 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         }
         // Subtrees of up to this many primitives are swept -- cluster tests, then culling rounds
         // over the surviving clusters -- rather than descended.
-        const int auto_treelet = 4096;
+        // Axis-aligned packets test a cluster's box against their origin rectangle (sharp: large
+        // subtrees pay, 16384 measured best on full frames and shards alike); other packets test
+        // the box's circumscribed sphere (blunt: 512, as without cluster tests).
+        const int auto_treelet = 512, auto_treelet_axis = 16384;
 #ifdef GRACE_PACKET_STATS
         a.treelet = g_treelet < 0 ? auto_treelet : g_treelet;
+        a.treelet_axis = g_treelet < 0 ? auto_treelet_axis : g_treelet;
 #else
         a.treelet = (MODE == MODE_STATS) ? 0 : (g_treelet < 0 ? auto_treelet : g_treelet);
+        a.treelet_axis = (MODE == MODE_STATS) ? 0 : (g_treelet < 0 ? auto_treelet_axis : g_treelet);
 #endif
         if (reorder) {
             uint32_t* ext = Workspace::take<uint32_t>(16);   // 12 extents + the device-side split

@@ -233,7 +233,8 @@ grace_status grace_trace_set_exact_integrals(int enabled);
 
 /* Subtrees with at most this many primitives are swept -- one test per cluster of 64 consecutive
  * primitives, then culling rounds over the surviving clusters -- instead of being descended
- * (results per ray unchanged).  0 disables; -1 (default) = 4096. */
+ * (results per ray unchanged).  0 disables; -1 (default) = 16384 for axis-aligned packets (whose
+ * cluster test is a sharp box-rectangle overlap), 512 for the others. */
 grace_status grace_trace_set_treelet_size(int max_primitives);
 
 /* Scene-constant trace data.  Every trace call derives, from the primitives and the tree alone,
