@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s of the SPH column-density trace (trace_cumulative_sph
-semantics) on the project_gadget workload -- 10^7 particles, 1024^2 orthographic rays
+semantics) on the project_gadget workload -- 10^7 particles, ONE 1024^2 orthographic image
 (BASELINE.json configs[3], the configuration the metric is quoted on; it fits one GPU).
 
     python bench.py --gpus N --steps K --warmup W
@@ -9,18 +9,26 @@ One process per GPU (torch.distributed / RCCL when N > 1): every rank builds the
 from the same seeded particles (the tree is replicated), traces its own contiguous shard of
 the job's ray batch, and the per-ray integrals are all-gathered over RCCL (the only
 collective; 4 B/ray).  A "step" = one trace of the whole ray batch (+ the gather when N > 1)
-with particles, tree and rays resident in HBM.
+with particles, tree, the scene's pre-pass records (grace_trace_prepare_f4: scene-constant,
+computed once after the build like the tree itself) and rays resident in HBM.
 
-  --scaling weak (default): the job is N frames of the 1024^2 image -- frame 0 is the
-      pixel-centre grid of configs[3], frame r > 0 the same grid shifted by a fixed sub-pixel
-      offset (an N-sample supersampled projection) -- so every rank traces 1024^2 rays of the
-      same statistical character whatever N is; a rank's contiguous shard is its frame.
-  --scaling strong: the job is the single 1024^2 frame, cut into N contiguous shards.
+  --scaling strong (default): the job is the single 1024^2 frame of configs[3], cut into N
+      contiguous ray shards -- BASELINE.json's "rays sharded over 8xMI355X".
+  --scaling weak: N frames of the 1024^2 image (frame r = the grid shifted by a fixed
+      sub-pixel offset), one frame per rank; an extra, never the headline.
 
 Rank 0 prints ONE JSON line.  The oracle is used only by the cpu_baseline leg (rank 0,
 N = 1) as the thing timed on the host cores, never in the GPU path.
+
+roofline: the traversal is NOT HBM-bound (its working set is cache-resident; measured HBM
+traffic is a few % of peak) -- its ceiling is VALU issue.  `achieved` / `peak` are vector
+wave-instructions per second: the kernel's SQ_INSTS_VALU per launch (rocprofv3 PMC pass
+committed under profiles/, keyed by the sha256 of csrc/trace.hip it was collected on; null
+when that no longer matches) over the kernel duration measured live in THIS run with HIP
+events, against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 fp32 instruction.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -33,7 +41,14 @@ sys.path.insert(0, os.path.join(ROOT, "grace-devel_amd"))
 import numpy as np
 import torch
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0            # HBM3E spec
+N_SIMDS = 256 * 4
+MAX_CLOCK_GHZ = 2.4
+VALU_PEAK_GINST = N_SIMDS * MAX_CLOCK_GHZ / 2.0   # v_fma_f32 wave64: 2 cycles per SIMD-32
+MIN_VALU_PER_HIT = 13   # sub sub mul mul add | sqrt mul min cvt fract shl | fma fma (csrc/trace.hip)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_trace.json")
+TRACE_SRC = os.path.join(ROOT, "grace-devel_amd", "csrc", "trace.hip")
 
 
 def make_particles(n, device, seed=42):
@@ -47,52 +62,119 @@ def make_particles(n, device, seed=42):
     return s
 
 
-def cpu_baseline(spheres_host, rays_host, seconds_target=15.0):
-    """The reference's host-side tree_traversal path (OpenMP brute-force sphere_hit over
-    every (ray, sphere) pair, tests/tree_traversal/tree_traversal.cu:65-79) with the
-    column-density accumulation, timed on this box's cores on a bounded ray sample."""
+def _cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(spheres_host, rays_host, tree_host, seconds_target=10.0):
+    """Host-core baselines, timed in this run on bounded samples (SURVEY.md 8d / BASELINE.md):
+
+    value -- the hot path itself on the CPU: the oracle's restatement of trace_kernel
+        (bintree_trace.cuh:52-197; packets of 32 consecutive rays sharing a stack, as a warp
+        does) + OnHit_sphere_cumulate, OpenMP over packets on all cores, over the SAME
+        particles and the tree the GPU built.  kind = "port".
+    tree_traversal -- the reference's own host path (tests/tree_traversal/tree_traversal.cu:
+        65-79): OpenMP brute-force sphere_hit over every (ray, sphere) pair, no BVH, on its
+        own geometry (config 2: 10^6 spheres, isotropic rays); pair tests/s and implied rays/s.
+    morton_key -- the tests/morton_key loop (generic/morton.h:32-42) over the particles, one
+        thread (as in the reference) and all threads.
+    """
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     O.build()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = _cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    nodes, leaves, root = tree_host
     n_rays = len(rays_host)
-    # Probe, then size the sample for ~seconds_target of work.
-    probe = rays_host[np.linspace(0, n_rays - 1, 4 * cores).astype(np.int64)]
-    t0 = time.perf_counter(); O.brute_cumulative(probe, spheres_host); t1 = time.perf_counter()
-    per_ray = max((t1 - t0) / len(probe), 1e-9)
-    n_sample = int(min(n_rays, max(4 * cores, seconds_target / per_ray)))
-    n_sample = max(cores, (n_sample // cores) * cores)
-    sample = rays_host[np.linspace(0, n_rays - 1, n_sample).astype(np.int64)]
-    t0 = time.perf_counter(); O.brute_cumulative(sample, spheres_host); t1 = time.perf_counter()
-    rate = n_sample / (t1 - t0)
-    # BASELINE.md's second host path: the tests/morton_key loop (morton_key(float,float,float),
-    # generic/morton.h:32-42) over the same particles, one thread (the loop is serial there too).
+
+    def runs_of_32(count):
+        """`count` packets of 32 consecutive rays, evenly spaced over the image."""
+        starts = (np.linspace(0, n_rays // 32 - 1, count).astype(np.int64)) * 32
+        return rays_host[(starts[:, None] + np.arange(32)[None, :]).reshape(-1)]
+
+    # -- the BVH walk (probe, then ~seconds_target of work)
+    probe = runs_of_32(cores)
+    t0 = time.perf_counter(); O.trace(probe, spheres_host, nodes, leaves, root, width=32, mode=1)
+    per_packet = max((time.perf_counter() - t0) / cores, 1e-6)   # one packet per core
+    n_pk = int(min(n_rays // 32, max(cores, seconds_target / per_packet * cores)))
+    n_pk = max(cores, (n_pk // cores) * cores)
+    sample = runs_of_32(n_pk)
+    t0 = time.perf_counter(); O.trace(sample, spheres_host, nodes, leaves, root, width=32, mode=1)
+    walk_s = time.perf_counter() - t0
+    walk_rate = len(sample) / walk_s
+
+    # -- tree_traversal: brute force, config 2 geometry (10^6 spheres r in U[0, 0.1), isotropic rays)
+    n2 = 1_000_000
+    s2 = O.random_real4(n2, (0, 0, 0, 0), (1, 1, 1, 0.1))
+    rng = np.random.default_rng(1234)
+    d = rng.normal(size=(4 * cores, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r2 = np.zeros((len(d), 7), np.float32); r2[:, :3] = d; r2[:, 3:6] = 0.5; r2[:, 6] = 2.0
+    t0 = time.perf_counter(); O.brute_hitcounts(r2, s2); per_ray = (time.perf_counter() - t0) / len(r2)
+    n_bf = max(cores, int(min(32000, 0.5 * seconds_target / max(per_ray, 1e-9))) // cores * cores)
+    d = rng.normal(size=(n_bf, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r2 = np.zeros((n_bf, 7), np.float32); r2[:, :3] = d; r2[:, 3:6] = 0.5; r2[:, 6] = 2.0
+    t0 = time.perf_counter(); O.brute_hitcounts(r2, s2); bf_s = time.perf_counter() - t0
+
+    # -- morton_key loop over the particles
     nk = min(len(spheres_host), 10_000_000)
     bot = spheres_host[:nk, :3].min(axis=0); top = spheres_host[:nk, :3].max(axis=0)
-    t2 = time.perf_counter(); O.morton_keys30(spheres_host[:nk], bot, top); t3 = time.perf_counter()
-    return {"value": rate / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "morton_key_Mkeys_per_s_1thread": nk / (t3 - t2) / 1e6,
-            "sample": "%d of %d rays (evenly spaced over the image) x %d spheres, brute-force "
-                      "sphere_hit + kernel-integral accumulation, %.1f s wall"
-                      % (n_sample, n_rays, len(spheres_host), t1 - t0),
-            "pair_tests_per_s": rate * len(spheres_host)}
+    keys = np.empty(nk, np.uint32)
+    O.morton_keys30(spheres_host[:nk], bot, top, all_threads=True, out=keys)      # touch pages
+    t0 = time.perf_counter(); O.morton_keys30(spheres_host[:nk], bot, top, out=keys); k1 = time.perf_counter() - t0
+    t0 = time.perf_counter(); O.morton_keys30(spheres_host[:nk], bot, top, all_threads=True, out=keys)
+    kn = time.perf_counter() - t0
+    return {
+        "value": walk_rate / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "algorithm": "BVH walk: the oracle's restatement of trace_kernel (32-ray packets, one "
+                     "stack per packet) + OnHit_sphere_cumulate, OpenMP over packets",
+        "sample": "%d packets of 32 consecutive rays (evenly spaced over the %d-ray image), same "
+                  "%d particles and the GPU-built tree, %.1f s wall"
+                  % (n_pk, n_rays, len(spheres_host), walk_s),
+        "tree_traversal": {
+            "algorithm": "brute_force all pairs (the reference's host path has no BVH): "
+                         "tests/tree_traversal/tree_traversal.cu:65-79",
+            "sample": "%d isotropic rays x %d spheres (config 2 geometry), %.1f s wall" % (n_bf, n2, bf_s),
+            "pair_tests_per_s": n_bf * n2 / bf_s, "implied_Mrays_per_s_at_1e6_spheres": n_bf / bf_s / 1e6,
+            "cores": cores},
+        "morton_key": {"keys": nk, "Mkeys_per_s_1_thread": nk / k1 / 1e6,
+                       "Mkeys_per_s_all_threads": nk / kn / 1e6, "cores": cores},
+    }
+
+
+def load_pmc(kernel_name):
+    """Counter values of `kernel_name` from the committed rocprofv3 PMC passes, or (None, why)
+    if they were collected on a different csrc/trace.hip than the one this library was built
+    from."""
+    try:
+        pmc = json.load(open(PMC_FILE))
+    except Exception as e:
+        return None, "no PMC file (%s)" % e
+    sha = hashlib.sha256(open(TRACE_SRC, "rb").read()).hexdigest()
+    if pmc.get("trace_hip_sha256") != sha:
+        return None, "stale: profiles/r02_pmc_trace.json was collected on trace.hip %s, this is %s" % (
+            str(pmc.get("trace_hip_sha256"))[:12], sha[:12])
+    k = pmc.get("kernels", {}).get(kernel_name)
+    if not k:
+        return None, "kernel %s not in the PMC file" % kernel_name
+    return dict(k, source=os.path.relpath(PMC_FILE, ROOT), trace_hip_sha256=sha[:16],
+                collected_at_commit=pmc.get("collected_at_commit")), None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=300)   # ~1 s timed region at N = 1
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--particles", type=int, default=10_000_000)
     ap.add_argument("--side", type=int, default=1024)
     ap.add_argument("--max-per-leaf", type=int, default=32)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prepare", action="store_true",
+                    help="recompute the scene's pre-pass records inside every trace call")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,35 +268,56 @@ def main():
     alg_bytes_total = 28 * n_rays + 64 * nodes_v + 16 * leaves_v + 16 * tested + 4 * n_rays
     gh.trace_status()
 
-    def step():
+    def trace_once():
         gh.trace_cumulative_sph(my_rays, spheres, tree, my_out[: r1 - r0])
+
+    def step():
+        trace_once()
         return sharding.gather_results(my_out, n_rays, world, dist)
+
+    # The same step without the prepared scene (every call then recomputes the per-sphere
+    # records, node spans and cluster boxes), for the record.
+    unprepared_ms = None
+    if not args.no_prepare:
+        trace_once(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            trace_once()
+        torch.cuda.synchronize()
+        unprepared_ms = 1e3 * (time.perf_counter() - t1) / 5
+        gh.trace_prepare(spheres, tree)
 
     for _ in range(args.warmup):
         image = step()
-    # HIP events directly around the traversal kernel on its stream (inside the library);
-    # read back after each step's launch -- the wait falls on the kernel that is timed anyway.
-    gh.enable_kernel_timing(True)
-    trace_ms = []
-    kern_ev = [(ev(), ev()) for _ in range(args.steps)]
+    # ---- the timed region: EXACTLY `steps` steps, nothing else in it, launches asynchronous --
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        kern_ev[k][0].record()
-        gh.trace_cumulative_sph(my_rays, spheres, tree, my_out[: r1 - r0])
-        kern_ev[k][1].record()
-        image = sharding.gather_results(my_out, n_rays, world, dist)
-        trace_ms.append(gh.last_kernel_ms())
+        image = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    call_ms = sum(a.elapsed_time(b) for a, b in kern_ev) / args.steps   # pre-passes + kernel
-    kern_ms = sum(trace_ms) / len(trace_ms)                             # trace_kernel alone
+
+    # ---- kernel and call durations: HIP events, after the timed region ----------------------
+    # In-library events sit directly around the traversal kernel on its stream
+    # (grace_trace_enable_timing); torch events around the whole call add the per-call ray
+    # coherence pass (extents, keys, partial sort).
+    gh.enable_kernel_timing(True)
+    k_rep = max(3, min(args.steps, 20))
+    trace_ms, call_ev = [], []
+    for _ in range(k_rep):
+        a, b = ev(), ev()
+        a.record(); trace_once(); b.record()
+        trace_ms.append(gh.last_kernel_ms())
+        call_ev.append((a, b))
+    torch.cuda.synchronize()
+    kern_ms = sum(trace_ms) / len(trace_ms)
+    call_ms = sum(a.elapsed_time(b) for a, b in call_ev) / len(call_ev)
     gh.enable_kernel_timing(False)
     t = torch.tensor([elapsed, kern_ms, call_ms], dtype=torch.float64, device=device)
     if world > 1:
@@ -230,11 +333,10 @@ def main():
     if world == 1:
         image = image.clone()          # keep the default-mode frame for the printed statistics
         gh.set_exact_integrals(True)
-        gh.trace_cumulative_sph(my_rays, spheres, tree, my_out[: r1 - r0])
-        torch.cuda.synchronize()
+        trace_once(); torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):
-            gh.trace_cumulative_sph(my_rays, spheres, tree, my_out[: r1 - r0])
+            trace_once()
         torch.cuda.synchronize()
         exact_ms = 1e3 * (time.perf_counter() - t1) / 3
         gh.set_exact_integrals(False)
@@ -242,27 +344,52 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_rays * args.steps / elapsed / 1e6
-        # Dominant kernel: trace_kernel<cumulative>.  One launch per rank per step; its
-        # algorithmic bytes are this job's total divided over the ranks.
+        # Dominant kernel: trace_kernel<cumulative>.  One launch per rank per step.
+        kernel_name = "trace_kernel<1, false, true>"     # MODE_CUMULATIVE, one wave per packet, fast integral
+        pmc, pmc_note = (None, "PMC passes are collected at N = 1 on the default workload")
+        if world == 1 and n == 10_000_000 and args.side == 1024 and args.max_per_leaf == 32:
+            pmc, pmc_note = load_pmc(kernel_name)
+        kern_s = kern_ms * 1e-3
         alg_per_launch = alg_bytes_total / world
-        achieved = alg_per_launch / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tfile) and world == 1 and n == 10_000_000 and args.side == 1024:
-            try:
-                traffic = json.load(open(tfile)).get("trace_cumulative_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         img = image[:frame_rays]   # frame 0
         # Compulsory bytes: everything the launch must read at least once --
         # the pre-pass records of all particles (16 + 8 B), every node (64 B + 8 B span) and
-        # leaf (16 B), this rank's rays (28 B) -- plus 4 B written per ray.
-        compulsory = (24 * n + 72 * (tree.n_leaves - 1) + 16 * tree.n_leaves
+        # leaf (16 B), the cluster boxes (32 B per 64 particles), this rank's rays (28 B) --
+        # plus 4 B written per ray.
+        compulsory = (24 * n + n // 2 + 72 * (tree.n_leaves - 1) + 16 * tree.n_leaves
                       + 32 * (n_rays // world))
-        measured = None
-        if traffic:
-            measured = {"GB/s": round(traffic / (kern_ms * 1e-3) / 1e9, 1),
-                        "frac_of_peak": round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        roof = {
+            "bound": "valu", "kernel": kernel_name, "unit": "G wave-instr/s",
+            "peak": VALU_PEAK_GINST, "achieved": None, "frac": None, "traffic": None,
+            "kernel_ms": round(kern_ms, 4), "call_ms": round(call_ms, 4),
+            "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 fp32 VALU instruction "
+                               "(MI355X_MICROARCH.md); int/cmp/cvt issue at half and sqrt at a "
+                               "quarter of that rate, so a mixed stream cannot reach it",
+            "pmc": pmc, "pmc_note": pmc_note,
+            # SURVEY.md 8d's figure: every ray's walk counted alone, no packet sharing, no cache
+            # credit.  NOT bytes this kernel moves (64 rays share each load; the scene is cache
+            # resident) -- kept for reference only.
+            "algorithmic_bytes_per_launch_unshared_8d": int(alg_per_launch),
+            "algorithmic_GBs_unshared_8d": round(alg_per_launch / kern_s / 1e9, 1),
+            "compulsory_bytes_per_launch": int(compulsory),
+            "measured_hbm": None, "algorithmic_valu_efficiency": None,
+            "per_ray_mean": {"nodes": nodes_v / n_rays, "leaves": leaves_v / n_rays,
+                             "spheres_tested": tested / n_rays, "hits": hits / n_rays},
+        }
+        if pmc:
+            insts = pmc["SQ_INSTS_VALU"]
+            roof["achieved"] = round(insts / kern_s / 1e9, 1)
+            roof["frac"] = round(insts / kern_s / 1e9 / VALU_PEAK_GINST, 4)
+            # hits x the minimal instruction count of one ray-sphere evaluation / 64 lanes
+            roof["algorithmic_valu_efficiency"] = round(hits * MIN_VALU_PER_HIT / 64.0 / insts, 4)
+            if pmc.get("FETCH_SIZE_KB") is not None and pmc.get("WRITE_SIZE_KB") is not None:
+                # gfx950: FETCH_SIZE counts 128-B requests as 64 B (guide, HBM section): x2
+                traffic = 2.0 * pmc["FETCH_SIZE_KB"] * 1024.0 + pmc["WRITE_SIZE_KB"] * 1024.0
+                roof["traffic"] = int(traffic)
+                roof["measured_hbm"] = {"GB/s": round(traffic / kern_s / 1e9, 1),
+                                        "frac_of_peak": round(traffic / kern_s / 1e9 / HBM_PEAK_GBS, 4),
+                                        "peak_GB/s": HBM_PEAK_GBS,
+                                        "vs_compulsory": round(traffic / compulsory, 2)}
         out = {
             "metric": "Mrays/s SPH column-density trace, 10^7 particles",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world,
@@ -275,27 +402,23 @@ def main():
                                                         args.max_per_leaf),
                        "particles": n, "rays": n_rays, "frames": frames,
                        "max_per_leaf": args.max_per_leaf,
+                       "scene_prepared": not args.no_prepare,
                        "sharding": "%d frame(s) of %d rays, contiguous ray shards over %d "
                                    "rank(s), BVH replicated, all_gather of 4 B/ray"
                                    % (frames, frame_rays, world)},
-            "roofline": {"bound": "hbm", "kernel": "trace_kernel<cumulative>",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel_ms": round(kern_ms, 4), "call_ms": round(call_ms, 4),
-                         "algorithmic_bytes_per_launch": int(alg_per_launch),
-                         "compulsory_bytes_per_launch": int(compulsory),
-                         "measured_hbm": measured,
-                         "per_ray_mean": {"nodes": nodes_v / n_rays, "leaves": leaves_v / n_rays,
-                                          "spheres_tested": tested / n_rays,
-                                          "hits": hits / n_rays}},
+            "roofline": roof,
             "build": dict(phases, n_leaves=tree.n_leaves,
                           total_ms=round(sum(phases.values()), 4)),
             "image": {"mean": float(img.mean()), "max": float(img.max())},
+            "unprepared_ms_per_call": None if unprepared_ms is None else round(unprepared_ms, 4),
             "bit_exact_integrals": None if exact_ms is None else
                 {"ms_per_step": round(exact_ms, 4), "Mrays/s": round(n_rays / exact_ms / 1e3, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), rays.cpu().numpy())
+            gh.trace_release()
+            tree_host = (tree.nodes.cpu().numpy().view(np.float32).reshape(-1, 16),
+                         tree.leaves.cpu().numpy(), int(tree.root_index.item()))
+            out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), rays.cpu().numpy(), tree_host)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -113,6 +113,24 @@ void go_morton_keys30_f4(const go_f4* prims, size_t n, const float* bot,
     }
 }
 
+/* The same loop over all host threads (bench.py's cpu_baseline reports it next to the serial
+ * one; the reference's tests/morton_key loop is serial). */
+void go_morton_keys30_f4_omp(const go_f4* prims, size_t n, const float* bot,
+                             const float* top, uint32_t* keys)
+{
+    const int span = (1u << 10) - 1;
+    float sx = span / (top[0] - bot[0]);
+    float sy = span / (top[1] - bot[1]);
+    float sz = span / (top[2] - bot[2]);
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t x = (uint32_t)(sx * (prims[i].x - bot[0]));
+        uint32_t y = (uint32_t)(sy * (prims[i].y - bot[1]));
+        uint32_t z = (uint32_t)(sz * (prims[i].z - bot[2]));
+        keys[i] = go_morton_key30(x, y, z);
+    }
+}
+
 /* Same, 63-bit keys, Real3 = float3 bounds (fp32 arithmetic). */
 void go_morton_keys63_f4(const go_f4* prims, size_t n, const float* bot,
                          const float* top, uint64_t* keys)

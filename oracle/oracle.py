@@ -90,11 +90,12 @@ def _rays(r):
 
 # -- Morton -------------------------------------------------------------------------
 
-def morton_keys30(prims, bot, top):
+def morton_keys30(prims, bot, top, all_threads=False, out=None):
     prims = _f4(prims)
-    keys = np.empty(len(prims), np.uint32)
+    keys = np.empty(len(prims), np.uint32) if out is None else out
     b = np.asarray(bot, np.float32); t = np.asarray(top, np.float32)
-    lib().go_morton_keys30_f4(_p(prims), C.c_size_t(len(prims)), _p(b), _p(t), _p(keys))
+    fn = lib().go_morton_keys30_f4_omp if all_threads else lib().go_morton_keys30_f4
+    fn(_p(prims), C.c_size_t(len(prims)), _p(b), _p(t), _p(keys))
     return keys
 
 
