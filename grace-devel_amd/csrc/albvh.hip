@@ -491,6 +491,23 @@ grace_status grace_albvh_build_d4(const double* d_spheres, size_t n, const float
                                               as_stream(stream));
 }
 
+// The remaining (Real4, DeltaType) instantiations of ALBVH_sph (build_sph.cuh:118-124).
+#define GRACE_ALBVH(NAME, PRIM_T, DELTA_T, PRIM_KIND)                                            \
+    grace_status NAME(const PRIM_T* d_spheres, size_t n, const DELTA_T* d_deltas,                \
+                      int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,                \
+                      size_t* h_n_leaves, grace_stream stream)                                   \
+    {                                                                                            \
+        return albvh_build<DELTA_T, PRIM_KIND>(reinterpret_cast<const float*>(d_spheres), n,     \
+                                               d_deltas, max_per_leaf, d_nodes, d_leaves,        \
+                                               d_root, h_n_leaves, as_stream(stream));           \
+    }
+GRACE_ALBVH(grace_albvh_build_f4_u64, float, uint64_t, PRIM_SPHERE)
+GRACE_ALBVH(grace_albvh_build_f4_f64, float, double, PRIM_SPHERE)
+GRACE_ALBVH(grace_albvh_build_d4_f64, double, double, PRIM_SPHERE_D4)
+GRACE_ALBVH(grace_albvh_build_d4_u32, double, uint32_t, PRIM_SPHERE_D4)
+GRACE_ALBVH(grace_albvh_build_d4_u64, double, uint64_t, PRIM_SPHERE_D4)
+#undef GRACE_ALBVH
+
 grace_status grace_albvh_enable_timing(int enabled)
 {
     g_phase_timing = enabled != 0;

@@ -48,19 +48,35 @@ __global__ __launch_bounds__(256) void sphere_deltas_kernel(const float4* __rest
     if (t < n) deltas[t + 1] = (t + 1 < n) ? sphere_delta<KIND>(a, b) : INFINITY;
 }
 
-// DeltaEuclidean on double4 spheres (generic/functors/albvh.h:44-74): differences and products
-// in double, the sum narrowed to the float the functor returns.  32 B per sphere, two reads.
+// DeltaEuclidean / DeltaSurfaceArea on double4 spheres (generic/functors/albvh.h:44-74,
+// 84-126).  Euclidean: differences and products in double, the sum narrowed to the float the
+// functor returns.  Surface area: AABBSphere forms centre -+ radius in double and narrows the
+// corners to float3 (generic/functors/aabb.h:9-26); the merged extents and the area are fp32.
+// Out = float, or double for a device_vector<double> of deltas (build_tree<double4>,
+// tests/helper/tree.cuh:20-24: the float value widened).  32 B per sphere, two reads.
+template <int KIND, typename Out>
 __global__ __launch_bounds__(256) void sphere_deltas_d4_kernel(const double* __restrict__ s, size_t n,
-                                                               float* __restrict__ deltas)
+                                                               Out* __restrict__ deltas)
 {
     const size_t t = blockIdx.x * size_t(blockDim.x) + threadIdx.x;
-    if (t == 0) deltas[0] = INFINITY;
+    if (t == 0) deltas[0] = Out(INFINITY);
     if (t >= n) return;
-    if (t + 1 >= n) { deltas[t + 1] = INFINITY; return; }
+    if (t + 1 >= n) { deltas[t + 1] = Out(INFINITY); return; }
     const double* a = s + 4 * t;
     const double* b = a + 4;
-    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
-    deltas[t + 1] = float(dx * dx + dy * dy + dz * dz);
+    if (KIND == DELTA_EUCLID) {
+        const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+        deltas[t + 1] = Out(float(dx * dx + dy * dy + dz * dz));
+    } else {
+        float L[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float bi = float(a[k] - a[3]), ti = float(a[k] + a[3]);
+            const float bj = float(b[k] - b[3]), tj = float(b[k] + b[3]);
+            L[k] = fmaxf(ti, tj) - fminf(bi, bj);
+        }
+        deltas[t + 1] = Out((L[0] * L[1]) + (L[0] * L[2]) + (L[1] * L[2]));
+    }
 }
 
 template <typename Key>
@@ -96,14 +112,20 @@ grace_status grace_deltas_area_f4(const float* d_spheres, size_t n, float* d_del
     return GRACE_OK;
 }
 
-grace_status grace_deltas_euclid_d4(const double* d_spheres, size_t n, float* d_deltas,
-                                    grace_stream stream)
-{
-    GRACE_REQUIRE(d_spheres && d_deltas && n > 0, "deltas: null pointer or empty input");
-    sphere_deltas_d4_kernel<<<ceil_div(n, 256), 256, 0, as_stream(stream)>>>(d_spheres, n, d_deltas);
-    GRACE_CHECK_LAUNCH();
-    return GRACE_OK;
-}
+#define GRACE_DELTAS_D4(NAME, KIND, OUT)                                                        \
+    grace_status NAME(const double* d_spheres, size_t n, OUT* d_deltas, grace_stream stream)     \
+    {                                                                                            \
+        GRACE_REQUIRE(d_spheres && d_deltas && n > 0, "deltas: null pointer or empty input");    \
+        sphere_deltas_d4_kernel<KIND, OUT><<<ceil_div(n, 256), 256, 0, as_stream(stream)>>>(     \
+            d_spheres, n, d_deltas);                                                             \
+        GRACE_CHECK_LAUNCH();                                                                    \
+        return GRACE_OK;                                                                         \
+    }
+GRACE_DELTAS_D4(grace_deltas_euclid_d4, DELTA_EUCLID, float)
+GRACE_DELTAS_D4(grace_deltas_euclid_d4_f64, DELTA_EUCLID, double)
+GRACE_DELTAS_D4(grace_deltas_area_d4, DELTA_AREA, float)
+GRACE_DELTAS_D4(grace_deltas_area_d4_f64, DELTA_AREA, double)
+#undef GRACE_DELTAS_D4
 
 grace_status grace_deltas_xor_u32(const uint32_t* d_keys, size_t n, uint32_t* d_deltas,
                                   grace_stream stream)

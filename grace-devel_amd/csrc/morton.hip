@@ -176,11 +176,11 @@ grace_status morton_keys(const float* d_spheres, size_t n, const Real* bot, cons
 // double4).  CentroidSphere (generic/functors/centroid.h:33-40) narrows the co-ordinates to
 // float BEFORE the key arithmetic, for double input too -- tests/morton_key_kernel/
 // 63bit_keys.cu:52-58 spells out that the host must cast to match.
-template <typename Key, typename Elem>
+template <typename Key, typename Elem, typename Real>
 __global__ __launch_bounds__(256) void morton_keys_points_kernel(const Elem* __restrict__ pts,
-                                                                 size_t n, int stride, float minx,
-                                                                 float miny, float minz, float sx,
-                                                                 float sy, float sz,
+                                                                 size_t n, int stride, Real minx,
+                                                                 Real miny, Real minz, Real sx,
+                                                                 Real sy, Real sz,
                                                                  Key* __restrict__ keys)
 {
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
@@ -195,28 +195,69 @@ __global__ __launch_bounds__(256) void morton_keys_points_kernel(const Elem* __r
     }
 }
 
-template <typename Key>
+template <typename Key, typename Real>
 grace_status morton_keys_points(const void* d_points, size_t n, int is_double, int stride,
-                                const float* bot, const float* top, Key* d_keys,
+                                const Real* bot, const Real* top, Key* d_keys,
                                 hipStream_t stream)
 {
     GRACE_REQUIRE(d_points && d_keys && bot && top, "morton_keys (points): null pointer");
     GRACE_REQUIRE(stride >= 3 && stride <= 16, "morton_keys (points): elements per point must be 3..16");
     if (n == 0) return GRACE_OK;
     const int span = sizeof(Key) > 4 ? (1u << 21) - 1 : (1u << 10) - 1;
-    const float sx = span / (top[0] - bot[0]);
-    const float sy = span / (top[1] - bot[1]);
-    const float sz = span / (top[2] - bot[2]);
+    const Real sx = span / (top[0] - bot[0]);
+    const Real sy = span / (top[1] - bot[1]);
+    const Real sz = span / (top[2] - bot[2]);
     if (is_double)
-        morton_keys_points_kernel<Key, double><<<stream_grid(n, 256), 256, 0, stream>>>(
+        morton_keys_points_kernel<Key, double, Real><<<stream_grid(n, 256), 256, 0, stream>>>(
             static_cast<const double*>(d_points), n, stride, bot[0], bot[1], bot[2], sx, sy, sz,
             d_keys);
     else
-        morton_keys_points_kernel<Key, float><<<stream_grid(n, 256), 256, 0, stream>>>(
+        morton_keys_points_kernel<Key, float, Real><<<stream_grid(n, 256), 256, 0, stream>>>(
             static_cast<const float*>(d_points), n, stride, bot[0], bot[1], bot[2], sx, sy, sz,
             d_keys);
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
+}
+
+// min / max of the float-narrowed x y z of generic points (compute_centroids + min_vec3 /
+// max_vec3 with CentroidSphere on double4 input, kernels/morton.cuh:139-174).
+template <typename Elem>
+__global__ __launch_bounds__(256) void points_minmax_kernel(const Elem* __restrict__ pts, size_t n,
+                                                            int stride, uint32_t* __restrict__ out8)
+{
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x) {
+        const Elem* q = pts + i * size_t(stride);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float c = static_cast<float>(q[k]);
+            lo[k] = fminf(lo[k], c);
+            hi[k] = fmaxf(hi[k], c);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+    __shared__ float s_lo[4][3], s_hi[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float l = s_lo[0][k], h = s_hi[0][k];
+        for (int w = 1; w < 4; ++w) { l = fminf(l, s_lo[w][k]); h = fmaxf(h, s_hi[w][k]); }
+        atomicMin(&out8[k], f2ord(l));
+        atomicMax(&out8[4 + k], f2ord(h));
+    }
 }
 
 // ---- triangle primitives: {v, e1, e2}, 9 floats (tests/profile_trace_triangle/triangle.cuh:11-25)
@@ -356,20 +397,71 @@ grace_status grace_morton_keys63_f4_d3(const float* d_spheres, size_t n, const d
     return morton_keys<uint64_t, double>(d_spheres, n, h_bot, h_top, d_keys, as_stream(stream));
 }
 
+grace_status grace_morton_keys30_f4_d3(const float* d_spheres, size_t n, const double* h_bot,
+                                       const double* h_top, uint32_t* d_keys,
+                                       grace_stream stream)
+{
+    return morton_keys<uint32_t, double>(d_spheres, n, h_bot, h_top, d_keys, as_stream(stream));
+}
+
+grace_status grace_centroid_bounds_points(const void* d_points, size_t n, int is_double,
+                                          int elems_per_point, float* h_bot, float* h_top,
+                                          grace_stream stream)
+{
+    GRACE_REQUIRE(d_points && n > 0 && h_bot && h_top, "centroid_bounds (points): bad argument");
+    GRACE_REQUIRE(elems_per_point >= 3 && elems_per_point <= 16,
+                  "centroid_bounds (points): elements per point must be 3..16");
+    hipStream_t st = as_stream(stream);
+    GRACE_TRY(Workspace::begin(256));
+    uint32_t* d_out = Workspace::take<uint32_t>(8);
+    GRACE_TRY_HIP(hipMemsetAsync(d_out, 0xFF, 16, st));
+    GRACE_TRY_HIP(hipMemsetAsync(d_out + 4, 0x00, 16, st));
+    if (is_double)
+        points_minmax_kernel<double><<<stream_grid(n, 256, 4), 256, 0, st>>>(
+            static_cast<const double*>(d_points), n, elems_per_point, d_out);
+    else
+        points_minmax_kernel<float><<<stream_grid(n, 256, 4), 256, 0, st>>>(
+            static_cast<const float*>(d_points), n, elems_per_point, d_out);
+    GRACE_CHECK_LAUNCH();
+    uint32_t h[8];
+    GRACE_TRY_HIP(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, st));
+    GRACE_TRY_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 3; ++k) { h_bot[k] = ord2f(h[k]); h_top[k] = ord2f(h[4 + k]); }
+    return GRACE_OK;
+}
+
+grace_status grace_morton_keys30_points_d3(const void* d_points, size_t n, int is_double,
+                                           int elems_per_point, const double* h_bot,
+                                           const double* h_top, uint32_t* d_keys,
+                                           grace_stream stream)
+{
+    return morton_keys_points<uint32_t, double>(d_points, n, is_double, elems_per_point, h_bot,
+                                                h_top, d_keys, as_stream(stream));
+}
+
+grace_status grace_morton_keys63_points_d3(const void* d_points, size_t n, int is_double,
+                                           int elems_per_point, const double* h_bot,
+                                           const double* h_top, uint64_t* d_keys,
+                                           grace_stream stream)
+{
+    return morton_keys_points<uint64_t, double>(d_points, n, is_double, elems_per_point, h_bot,
+                                                h_top, d_keys, as_stream(stream));
+}
+
 grace_status grace_morton_keys30_points(const void* d_points, size_t n, int is_double,
                                         int elems_per_point, const float* h_bot,
                                         const float* h_top, uint32_t* d_keys, grace_stream stream)
 {
-    return morton_keys_points<uint32_t>(d_points, n, is_double, elems_per_point, h_bot, h_top,
-                                        d_keys, as_stream(stream));
+    return morton_keys_points<uint32_t, float>(d_points, n, is_double, elems_per_point, h_bot, h_top,
+                                               d_keys, as_stream(stream));
 }
 
 grace_status grace_morton_keys63_points(const void* d_points, size_t n, int is_double,
                                         int elems_per_point, const float* h_bot,
                                         const float* h_top, uint64_t* d_keys, grace_stream stream)
 {
-    return morton_keys_points<uint64_t>(d_points, n, is_double, elems_per_point, h_bot, h_top,
-                                        d_keys, as_stream(stream));
+    return morton_keys_points<uint64_t, float>(d_points, n, is_double, elems_per_point, h_bot, h_top,
+                                               d_keys, as_stream(stream));
 }
 
 } // extern "C"

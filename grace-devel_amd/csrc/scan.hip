@@ -439,6 +439,22 @@ __global__ __launch_bounds__(256) void multiply_by_weights_kernel(
         out[i] = w[map[i]] * x[i];
 }
 
+// 64-bit sum of non-negative int32 counts (one atomic per workgroup).
+__global__ __launch_bounds__(256) void sum_i32_u64_kernel(const int* __restrict__ in, size_t n,
+                                                          unsigned long long* __restrict__ total)
+{
+    unsigned long long acc = 0;
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x)
+        acc += (unsigned long long)(uint32_t)in[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    __shared__ unsigned long long s_acc[4];
+    if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(total, s_acc[0] + s_acc[1] + s_acc[2] + s_acc[3]);
+}
+
 } // namespace
 
 extern "C" {
@@ -448,15 +464,25 @@ grace_status grace_scan_exclusive_i32(const int* d_in, size_t n, int* d_out, lon
 {
     GRACE_REQUIRE(n == 0 || (d_in && d_out), "scan: null pointer");
     hipStream_t st = as_stream(stream);
-    GRACE_TRY(Workspace::begin((scan_ws_count(n) + 64) * sizeof(uint32_t)));
-    uint32_t* d_total = Workspace::take<uint32_t>(1);
+    GRACE_TRY(Workspace::begin((scan_ws_count(n) + 128) * sizeof(uint32_t)));
+    unsigned long long* d_total = Workspace::take<unsigned long long>(1);
     uint32_t* scratch = Workspace::take<uint32_t>(scan_ws_count(n));
-    GRACE_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t*>(d_in),
-                                 reinterpret_cast<uint32_t*>(d_out), n, scratch,
-                                 h_total ? d_total : nullptr, st));
     if (h_total) {
-        uint32_t t = 0;
-        GRACE_TRY_HIP(hipMemcpyAsync(&t, d_total, 4, hipMemcpyDeviceToHost, st));
+        // The grand total in 64 bits, taken BEFORE the scan (d_out may alias d_in): the scan
+        // itself wraps modulo 2^32 like the reference's int scan (trace_sph.cuh:135-137), and
+        // the callers must be able to tell (offsets past INT32_MAX cannot address the per-hit
+        // arrays).
+        GRACE_TRY_HIP(hipMemsetAsync(d_total, 0, 8, st));
+        if (n) {
+            sum_i32_u64_kernel<<<stream_grid(n, 256, 4), 256, 0, st>>>(d_in, n, d_total);
+            GRACE_CHECK_LAUNCH();
+        }
+    }
+    GRACE_TRY(exclusive_scan_u32(reinterpret_cast<const uint32_t*>(d_in),
+                                 reinterpret_cast<uint32_t*>(d_out), n, scratch, nullptr, st));
+    if (h_total) {
+        unsigned long long t = 0;
+        GRACE_TRY_HIP(hipMemcpyAsync(&t, d_total, 8, hipMemcpyDeviceToHost, st));
         GRACE_TRY_HIP(hipStreamSynchronize(st));
         *h_total = (long long)t;
     }

@@ -75,13 +75,23 @@ __device__ __forceinline__ uint32_t dist_key(float d)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(64 * SEG_WAVES) void segsort_wave_kernel(
-    float* __restrict__ dist, const int* __restrict__ offsets, size_t n_seg, size_t n,
-    int* __restrict__ hidx, float* __restrict__ data, uint32_t* __restrict__ k0,
-    uint32_t* __restrict__ k1, uint32_t* __restrict__ i0, uint32_t* __restrict__ i1,
-    float* __restrict__ t_d, int* __restrict__ t_i, float* __restrict__ t_w)
+__device__ __forceinline__ uint64_t dist_key(double d)
 {
-    __shared__ uint32_t s_base[SEG_WAVES][4][256];   // one digit histogram per pass
+    if (d == 0.0) d = 0.0;
+    const uint64_t u = uint64_t(__double_as_longlong(d));
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// Real = float (Key uint32_t, four digit passes) or double (Key uint64_t, eight).
+template <typename Real, typename Key>
+__global__ __launch_bounds__(64 * SEG_WAVES) void segsort_wave_kernel(
+    Real* __restrict__ dist, const int* __restrict__ offsets, size_t n_seg, size_t n,
+    int* __restrict__ hidx, Real* __restrict__ data, Key* __restrict__ k0,
+    Key* __restrict__ k1, uint32_t* __restrict__ i0, uint32_t* __restrict__ i1,
+    Real* __restrict__ t_d, int* __restrict__ t_i, Real* __restrict__ t_w)
+{
+    constexpr int PASSES = int(sizeof(Key));
+    __shared__ uint32_t s_base[SEG_WAVES][PASSES][256];   // one digit histogram per pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t seg = size_t(blockIdx.x) * SEG_WAVES + wave;
     if (seg >= n_seg) return;
@@ -91,20 +101,20 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void segsort_wave_kernel(
     const int len = int(end - beg);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    // all four digit histograms in one read of the distances
+    // all digit histograms in one read of the distances
 #pragma unroll
-    for (int b = 0; b < 16; ++b) (&s_base[wave][0][0])[16 * lane + b] = 0;
+    for (int b = 0; b < 4 * PASSES; ++b) (&s_base[wave][0][0])[4 * PASSES * lane + b] = 0;
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < len; i += 64) {
-        const uint32_t key = dist_key(dist[beg + i]);
+        const Key key = dist_key(dist[beg + i]);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) atomicAdd(&s_base[wave][p][(key >> (8 * p)) & 255u], 1u);
+        for (int p = 0; p < PASSES; ++p) atomicAdd(&s_base[wave][p][uint32_t(key >> (8 * p)) & 255u], 1u);
     }
     __builtin_amdgcn_wave_barrier();
 
-    uint32_t* kin = k0; uint32_t* kout = k1;
+    Key* kin = k0; Key* kout = k1;
     uint32_t* iin = i0; uint32_t* iout = i1;
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < PASSES; ++pass) {
         const int shift = 8 * pass;
         uint32_t* base = s_base[wave][pass];
         // exclusive scan of the 256 counters: four per lane, then across the wave
@@ -125,12 +135,13 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void segsort_wave_kernel(
         for (int t0 = 0; t0 < len; t0 += 64) {
             const int i = t0 + lane;
             const bool valid = i < len;
-            uint32_t key = 0, idx = uint32_t(i);
+            Key key = 0;
+            uint32_t idx = uint32_t(i);
             if (valid) {
                 key = pass == 0 ? dist_key(dist[beg + i]) : kin[beg + i];
                 if (pass != 0) idx = iin[beg + i];
             }
-            const uint32_t d = (key >> shift) & 255u;
+            const uint32_t d = uint32_t(key >> shift) & 255u;
             unsigned long long same = __ballot(valid);
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
@@ -149,10 +160,10 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void segsort_wave_kernel(
         }
         // the next pass (other lanes of this wave) reads what this pass wrote
         __threadfence_block();   // same CU, same L1: workgroup scope is enough (no L2 write-back)
-        uint32_t* t = kin; kin = kout; kout = t;
-        t = iin; iin = iout; iout = t;
+        Key* tk = kin; kin = kout; kout = tk;
+        uint32_t* t = iin; iin = iout; iout = t;
     }
-    // after four passes the sorted order sits in iin (= i0): gather, then copy back
+    // after an even number of passes the sorted order sits in iin (= i0): gather, then copy back
     for (int i = lane; i < len; i += 64) {
         const size_t src = beg + iin[beg + i];
         t_d[beg + i] = dist[src];
@@ -190,7 +201,7 @@ grace_status grace_sort_by_distance_f32(float* d_distances, const int* d_ray_off
         float* t_d = Workspace::take<float>(n_hits);
         int* t_i = Workspace::take<int>(n_hits);
         float* t_w = Workspace::take<float>(n_hits);
-        segsort_wave_kernel<<<ceil_div(n_rays, size_t(SEG_WAVES)), 64 * SEG_WAVES, 0, st>>>(
+        segsort_wave_kernel<float, uint32_t><<<ceil_div(n_rays, size_t(SEG_WAVES)), 64 * SEG_WAVES, 0, st>>>(
             d_distances, d_ray_offsets, n_rays, n_hits, d_hit_indices, d_hit_data, k0, k1, i0, i1,
             t_d, t_i, t_w);
         GRACE_CHECK_LAUNCH();
@@ -233,6 +244,31 @@ grace_status grace_sort_by_distance_f32(float* d_distances, const int* d_ray_off
         gather_kernel<float><<<grid, 256, 0, st>>>(tmp, perm, n_hits, d_hit_data);
         GRACE_CHECK_LAUNCH();
     }
+    return GRACE_OK;
+}
+
+// sort_by_distance<double, int, double> (sort.cuh:97-131 with the double outputs of
+// trace_sph<double4, int, double>): one wavefront per segment, eight digit passes.
+grace_status grace_sort_by_distance_f64(double* d_distances, const int* d_ray_offsets,
+                                        size_t n_rays, size_t n_hits, int* d_hit_indices,
+                                        double* d_hit_data, grace_stream stream)
+{
+    GRACE_REQUIRE(n_hits == 0 || (d_distances && d_ray_offsets), "sort_by_distance: null pointer");
+    GRACE_REQUIRE(n_hits < (size_t(1) << 32), "sort_by_distance: at most 2^32 - 1 hits");
+    if (n_hits < 2 || n_rays == 0) return GRACE_OK;
+    hipStream_t st = as_stream(stream);
+    GRACE_TRY(Workspace::begin(4 * Workspace::aligned(n_hits * 8) + 3 * Workspace::aligned(n_hits * 4) + 1024));
+    uint64_t* k0 = Workspace::take<uint64_t>(n_hits);
+    uint64_t* k1 = Workspace::take<uint64_t>(n_hits);
+    uint32_t* i0 = Workspace::take<uint32_t>(n_hits);
+    uint32_t* i1 = Workspace::take<uint32_t>(n_hits);
+    double* t_d = Workspace::take<double>(n_hits);
+    int* t_i = Workspace::take<int>(n_hits);
+    double* t_w = Workspace::take<double>(n_hits);
+    segsort_wave_kernel<double, uint64_t><<<ceil_div(n_rays, size_t(SEG_WAVES)), 64 * SEG_WAVES, 0, st>>>(
+        d_distances, d_ray_offsets, n_rays, n_hits, d_hit_indices, d_hit_data, k0, k1, i0, i1,
+        t_d, t_i, t_w);
+    GRACE_CHECK_LAUNCH();
     return GRACE_OK;
 }
 

@@ -101,7 +101,11 @@ __constant__ double c_kernel_table[N_TABLE] = {
     0.000000000000000E+000
 };
 
-enum { MODE_COUNT = 0, MODE_CUMULATIVE = 1, MODE_HITS = 2, MODE_STATS = 3, MODE_TRI = 4 };
+enum { MODE_COUNT = 0, MODE_CUMULATIVE = 1, MODE_HITS = 2, MODE_STATS = 3, MODE_TRI = 4,
+       // Real4 = double4, Real = double (trace_sph.cuh:57-241 instantiated in double): the walk and
+       // every cull run on float records that CONTAIN the double spheres; each survivor is then
+       // tested and integrated in double against the caller's double4 record.
+       MODE_COUNT_D4 = 5, MODE_CUM_D4 = 6, MODE_HITS_D4 = 7 };
 
 struct TraceArgs {
     const float* rays;      // 7 floats per ray
@@ -116,6 +120,10 @@ struct TraceArgs {
     const float4* C;        // pre-pass: per CLUSTER (64 consecutive primitives) {lo.xyz, -}, {hi.xyz, -}:
                             // the box of the member spheres, slightly inflated (cluster_boxes_kernel)
     const double* T64;      // MODE_TRI pre-pass: {v, e1, e2} widened to fp64, 9 per triangle
+    const double* spheres_d; // *_D4 modes: the caller's double4 spheres
+    double* out_sums_d;      // MODE_CUM_D4
+    double* hit_integral_d;  // MODE_HITS_D4
+    double* hit_dist_d;
     int split;              // waves per packet (1, 2, 4, 8); each owns SUM_CLASSES / split classes
     int n_prims;
     float* partial;         // split > 1, cumulative: [n_rays][split] subtree sums
@@ -263,6 +271,27 @@ __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __rest
         }
         A[i] = a;
         if (B) B[i] = b;
+    }
+}
+
+// double4 spheres: the float record {x, y, z, r^2} that drives the walk's culls must CONTAIN the
+// double sphere -- the centre is narrowed (error <= half a float ulp per co-ordinate) and the
+// double hit test is close to exact, so the radius is inflated by 2^-18 relative plus 2^-21 of
+// the co-ordinate magnitudes before squaring (the float culls' own margins then cover their own
+// rounding as for float spheres).
+__global__ __launch_bounds__(256) void trace_prepass_d4_kernel(const double* __restrict__ spheres,
+                                                               size_t n, float4* __restrict__ A)
+{
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n + 4;
+         i += size_t(gridDim.x) * blockDim.x) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+            const double* s = spheres + 4 * i;
+            const double r = fabs(s[3]) * (1.0 + 3.814697265625e-06)
+                + (fabs(s[0]) + fabs(s[1]) + fabs(s[2]) + fabs(s[3])) * 4.76837158203125e-07;
+            a = make_float4(float(s[0]), float(s[1]), float(s[2]), float(r * r * (1.0 + 1e-6)));
+        }
+        A[i] = a;
     }
 }
 
@@ -680,7 +709,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     __shared__ float2 s_lutf[FAST ? N_TABLE + 1 : 1];
     // Per-wave tile of the candidates of the current culling round (MODE_TRI keeps its
     // fp64 triangles on the scalar path).
-    constexpr bool LDS_TILE = (MODE != MODE_TRI);
+    constexpr bool D4 = (MODE == MODE_COUNT_D4 || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4);
+    constexpr bool LDS_TILE = (MODE != MODE_TRI && !D4);
     // Three 8-byte planes per wave -- (x, y), (z, h^2), (1/h terms) -- so that one address
     // (plane base + 8 j) serves all of a survivor's reads through immediate offsets.
     // (66 slots: the survivor loop reads up to two slots past the round's last survivor)
@@ -704,7 +734,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     const int vblock = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + slot;
     const int wave_id = __builtin_amdgcn_readfirstlane(vblock * (TRACE_BLOCK / 64)
                                                        + (threadIdx.x >> 6));
-    if (MODE == MODE_CUMULATIVE || MODE == MODE_HITS) {
+    if (MODE == MODE_CUMULATIVE || MODE == MODE_HITS || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4) {
         if (threadIdx.x < N_TABLE + (FAST ? 1 : 0)) {
             const int i0 = threadIdx.x < N_TABLE ? threadIdx.x : N_TABLE - 1;
             const double y0 = c_kernel_table[i0];
@@ -760,7 +790,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
 
     // Axis-aligned packet?  (wave-uniform; tail lanes replicate a valid ray)
     int axis = -1;
-    if (MODE != MODE_HITS && MODE != MODE_TRI) {
+    if (MODE != MODE_HITS && MODE != MODE_TRI && MODE != MODE_HITS_D4) {
         const unsigned long long all = ~0ull;
         const bool zx = dx == 0.f, zy = dy == 0.f, zz = dz == 0.f;
         if (__builtin_amdgcn_ballot_w64(zy && zz && fabsf(dx) == 1.f) == all) axis = 0;
@@ -886,7 +916,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     int tri_data = -1;
     float tri_tmin = len * (1.f + 0.000001f);
     const double ddx = dx, ddy = dy, ddz = dz;
-    if (MODE == MODE_HITS) write_at = a.offsets[ray_index];
+    if (MODE == MODE_HITS || MODE == MODE_HITS_D4) write_at = a.offsets[ray_index];
+    double sum_d = 0.0;     // MODE_CUM_D4: one running double sum per ray, ascending primitive index
+    const double rdx = dx, rdy = dy, rdz = dz;
     // MODE_HITS: every ray owns a contiguous output segment, so lanes writing hit by hit
     // touch 64 different cache lines per store and the partial lines thrash L2 (measured:
     // 48 GB/s of useful output).  Hits are staged per lane in LDS (HIT_CAP entries, entry-major,
@@ -1139,7 +1171,39 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                 // index; 0 for the compacted tiles, which do not need it).
                 auto process = [&](auto lean_tag, const float4 s, const float2 sb, const int jj) {
                     constexpr bool LEAN = decltype(lean_tag)::value;
-                    if (MODE == MODE_TRI) {
+                    if constexpr (D4) {
+                        // sphere_hit<double4, double> (generic/intersect.h:16-54: ray members are
+                        // float, everything else double) and OnHit_sphere_cumulate / _individual with
+                        // Real = double (functors/trace.cuh:164-186, 196-235: ir = 1.f / w,
+                        // b = (N - 1) (sqrt(b2) ir), lerp<double> with the device branch's fma,
+                        // integral *= ir ir), on the caller's double4 record (wave-uniform load).
+                        const double* sp = a.spheres_d + 4 * size_t(jj);
+                        const double sx = sp[0], sy = sp[1], sz = sp[2], sw = sp[3];
+                        const double px = sx - ox, py = sy - oy, pz = sz - oz;
+                        const double dot_p = px * rdx + py * rdy + pz * rdz;
+                        const double bx = px - dot_p * rdx, by = py - dot_p * rdy, bz = pz - dot_p * rdz;
+                        const double b2 = bx * bx + by * by + bz * bz;
+                        const bool hit = !(b2 >= sw * sw) && !(dot_p < 0.0f) && !(dot_p >= len);
+                        if (MODE == MODE_COUNT_D4) {
+                            count += hit ? 1 : 0;
+                        } else if (hit) {
+                            const double ir = 1.f / sw;
+                            double x = (N_TABLE - 1) * (sqrt(b2) * ir);
+                            int x_idx = static_cast<int>(x);
+                            if (x_idx >= N_TABLE - 1) { x = double(N_TABLE - 1); x_idx = N_TABLE - 2; }
+                            const double2 y = s_lut[x_idx];
+                            double integral = __builtin_fma(x - x_idx, y.y, y.x);
+                            integral *= (ir * ir);
+                            if (MODE == MODE_CUM_D4) {
+                                sum_d += integral;
+                            } else if (valid) {
+                                a.hit_idx[write_at] = jj;
+                                a.hit_integral_d[write_at] = integral;
+                                a.hit_dist_d[write_at] = dot_p;
+                                ++write_at;
+                            }
+                        }
+                    } else if (MODE == MODE_TRI) {
                         // RayIntersect_tri + OnHit_tri (tris_trace.cuh:24-61)
                         float t;
                         if (tri_intersect(ddx, ddy, ddz, ox, oy, oz, a.T64 + 9 * size_t(jj), &t)) {
@@ -1235,7 +1299,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                         // Keep the reads here -- ahead of the survivors in between -- instead of
                         // letting the scheduler sink them next to their use.
                         __builtin_amdgcn_sched_barrier(0);
-                    } else {
+                    } else if (!D4) {
                         c = a.A[jj];
                     }
                 };
@@ -1292,6 +1356,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
         else if (count) atomicAdd(&a.out_counts[ray_index], count); // output zeroed by the host
     }
     if (MODE == MODE_TRI) a.out_counts[ray_index] = tri_data;
+    if (MODE == MODE_COUNT_D4) a.out_counts[ray_index] = count;
+    if (MODE == MODE_CUM_D4) a.out_sums_d[ray_index] = sum_d;
     if (MODE == MODE_CUMULATIVE) {
         if (cur_granule >= 0) s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane] = sum;
         // Pairwise sum of this wave's classes (a subtree of the summation tree).
@@ -1453,17 +1519,22 @@ grace_status scene_release()
     return GRACE_OK;
 }
 
-// Fills the scene-constant arrays (any of B1 / B50 / T64 may be null).
-grace_status scene_fill(bool tri, const void* prims, size_t n_prims, const float4* nodes,
+// Fills the scene-constant arrays (any of B1 / B50 / T64 may be null).  kind: 0 float4 spheres,
+// 1 triangles, 2 double4 spheres.
+grace_status scene_fill(int kind, const void* prims, size_t n_prims, const float4* nodes,
                         size_t n_nodes, const int4* leaves, float4* A, float2* B1, float2* B50,
                         double* T64, int2* node_prims, float4* C, hipStream_t stream)
 {
     node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
         reinterpret_cast<const int4*>(nodes), leaves, int(n_nodes), node_prims);
     GRACE_CHECK_LAUNCH();
-    if (tri) {
+    if (kind == 1) {
         tri_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
             static_cast<const float*>(prims), n_prims, A, T64);
+        GRACE_CHECK_LAUNCH();
+    } else if (kind == 2) {
+        trace_prepass_d4_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
+            static_cast<const double*>(prims), n_prims, A);
         GRACE_CHECK_LAUNCH();
     } else {
         trace_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
@@ -1502,7 +1573,7 @@ grace_status scene_prepare(bool tri, const void* prims, size_t n_prims, const in
     if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.C), 2 * ((n_prims + 63) / 64) * sizeof(float4));
     g_scene = sc;   // so that a failure below releases what was allocated
     if (st != GRACE_OK) { scene_release(); return st; }
-    st = scene_fill(tri, prims, n_prims, reinterpret_cast<const float4*>(d_nodes), n_nodes,
+    st = scene_fill(tri ? 1 : 0, prims, n_prims, reinterpret_cast<const float4*>(d_nodes), n_nodes,
                     reinterpret_cast<const int4*>(d_leaves), sc.A, sc.B1, sc.B50, sc.T64,
                     sc.node_prims, sc.C, stream);
     if (st != GRACE_OK) { scene_release(); return st; }
@@ -1541,7 +1612,8 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         constexpr bool need_b = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
         const bool fast_b = MODE == MODE_CUMULATIVE && !g_exact_integrals;
         const bool reorder = g_ray_reorder && n_rays > 64;
-        const bool cached = g_scene.valid && g_scene.tri == (MODE == MODE_TRI)
+        constexpr bool D4 = (MODE == MODE_COUNT_D4 || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4);
+        const bool cached = !D4 && g_scene.valid && g_scene.tri == (MODE == MODE_TRI)
             && g_scene.prims == static_cast<const void*>(a.spheres) && g_scene.n_prims == n_spheres
             && g_scene.nodes == static_cast<const void*>(a.nodes) && g_scene.n_nodes == n_nodes
             && g_scene.leaves == static_cast<const void*>(a.leaves);
@@ -1569,7 +1641,8 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             double* T64 = (MODE == MODE_TRI) ? Workspace::take<double>(9 * (n_spheres + 4)) : nullptr;
             int2* node_prims = Workspace::take<int2>(n_nodes);
             float4* C = Workspace::take<float4>(2 * n_clusters);
-            GRACE_TRY(scene_fill(MODE == MODE_TRI, a.spheres, n_spheres, a.nodes, n_nodes, a.leaves, A,
+            GRACE_TRY(scene_fill(MODE == MODE_TRI ? 1 : D4 ? 2 : 0,
+                                 D4 ? static_cast<const void*>(a.spheres_d) : a.spheres, n_spheres, a.nodes, n_nodes, a.leaves, A,
                                  fast_b ? nullptr : B, fast_b ? B : nullptr, T64, node_prims, C, stream));
             a.A = A; a.B = B; a.T64 = T64; a.node_prims = node_prims; a.C = C;
         }
@@ -1626,7 +1699,8 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     // 2-4x the waves, each with a tighter beam, on a chip that would otherwise sit idle.
     int width = 64;
     if (g_width > 0) width = g_width;
-    else if ((MODE == MODE_HITS && !hits_split) || MODE == MODE_TRI)
+    else if ((MODE == MODE_HITS && !hits_split) || MODE == MODE_TRI || MODE == MODE_COUNT_D4
+             || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4)
         while (width > 16 && ceil_div(n_rays, size_t(width)) < 4096) width /= 2;
     a.width = width;
     const int n_packets = ceil_div(n_rays, size_t(width));
@@ -1795,6 +1869,60 @@ grace_status grace_trace_closest_tri(const void* d_rays, size_t n_rays, const fl
     a.out_counts = d_closest;
     return launch_trace<MODE_TRI>(a, n_rays, n_tris, n_nodes, as_stream(stream));
 }
+
+// ---- double4 spheres (Real4 = double4, Real = double) ----------------------------------------
+static TraceArgs d4_args(const void* d_rays, const double* d_spheres, const int* d_nodes,
+                         const int* d_leaves, const int* d_root)
+{
+    TraceArgs a = {};
+    a.rays = static_cast<const float*>(d_rays);
+    a.spheres = reinterpret_cast<const float4*>(d_spheres);   // (non-null check only)
+    a.spheres_d = d_spheres;
+    a.nodes = reinterpret_cast<const float4*>(d_nodes);
+    a.leaves = reinterpret_cast<const int4*>(d_leaves);
+    a.root = d_root;
+    return a;
+}
+
+grace_status grace_trace_hitcounts_d4(const void* d_rays, size_t n_rays, const double* d_spheres,
+                                      size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                      const int* d_leaves, const int* d_root, int* d_hit_counts,
+                                      grace_stream stream)
+{
+    GRACE_REQUIRE(d_hit_counts, "trace_hitcounts (double4): null output");
+    TraceArgs a = d4_args(d_rays, d_spheres, d_nodes, d_leaves, d_root);
+    a.out_counts = d_hit_counts;
+    return launch_trace<MODE_COUNT_D4>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_trace_cumulative_d4(const void* d_rays, size_t n_rays, const double* d_spheres,
+                                       size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                       const int* d_leaves, const int* d_root, double* d_sums,
+                                       grace_stream stream)
+{
+    GRACE_REQUIRE(d_sums, "trace_cumulative (double4): null output");
+    TraceArgs a = d4_args(d_rays, d_spheres, d_nodes, d_leaves, d_root);
+    a.out_sums_d = d_sums;
+    return launch_trace<MODE_CUM_D4>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_trace_hits_d4(const void* d_rays, size_t n_rays, const double* d_spheres,
+                                 size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                 const int* d_leaves, const int* d_root, const int* d_ray_offsets,
+                                 int* d_hit_indices, double* d_hit_integrals,
+                                 double* d_hit_distances, grace_stream stream)
+{
+    GRACE_REQUIRE(d_ray_offsets && d_hit_indices && d_hit_integrals && d_hit_distances,
+                  "trace_hits (double4): null output");
+    TraceArgs a = d4_args(d_rays, d_spheres, d_nodes, d_leaves, d_root);
+    a.offsets = d_ray_offsets;
+    a.hit_idx = d_hit_indices;
+    a.hit_integral_d = d_hit_integrals;
+    a.hit_dist_d = d_hit_distances;
+    return launch_trace<MODE_HITS_D4>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_trace_status_d4(grace_stream stream) { return grace_trace_status(stream); }
 
 grace_status grace_trace_stats_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
                                   size_t n_spheres, const int* d_nodes, size_t n_nodes,

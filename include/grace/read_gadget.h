@@ -1,7 +1,8 @@
 // read_gadget.h -- Gadget-2 (format 1) reader for gas positions + smoothing lengths,
 // the role of the reference's tests/helper/read_gadget.cuh:69-159 (block order POS, VEL, ID,
 // [MASS], U, RHO, HSML; 256-byte header with npart[6], mass[6]; 4-byte block markers).
-// Host-only; returns spheres {x, y, z, h} ready for grace::device_vector<grace::float4>.
+// Host-only; fills spheres {x, y, z, h} (any float4-like record with .x .y .z .w: HIP's float4
+// for the thrust drop-in headers, grace::float4 for the HIP-free mirror).
 #pragma once
 
 #include <cstdint>
@@ -10,9 +11,8 @@
 #include <string>
 #include <vector>
 
-#include "grace/grace.h"
-
-inline void read_gadget(const std::string& fname, std::vector<grace::float4>& h_spheres)
+template <typename Float4>
+inline void read_gadget(const std::string& fname, std::vector<Float4>& h_spheres)
 {
     std::FILE* f = std::fopen(fname.c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open Gadget file " + fname);

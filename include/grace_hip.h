@@ -92,6 +92,27 @@ grace_status grace_morton_keys63_points(const void* d_points, size_t n, int is_d
                                         int elems_per_point, const float* h_bot,
                                         const float* h_top, uint64_t* d_keys, grace_stream stream);
 
+/* The remaining (point type, bounds type, key type) instantiations of grace::morton_keys
+ * (kernels/morton.cuh:97-189): float4 spheres with double3 bounds and 30-bit keys; generic
+ * points with double3 bounds (scale and key arithmetic in double on the float-narrowed
+ * co-ordinates); and the centroid bounds of generic points (the bounds-free overloads for
+ * Real4 = double4: compute_centroids + min/max of the float3 centroids, morton.cuh:139-174).
+ * grace_centroid_bounds_points synchronises. */
+grace_status grace_morton_keys30_f4_d3(const float* d_spheres, size_t n, const double* h_bot,
+                                       const double* h_top, uint32_t* d_keys,
+                                       grace_stream stream);
+grace_status grace_centroid_bounds_points(const void* d_points, size_t n, int is_double,
+                                          int elems_per_point, float* h_bot, float* h_top,
+                                          grace_stream stream);
+grace_status grace_morton_keys30_points_d3(const void* d_points, size_t n, int is_double,
+                                           int elems_per_point, const double* h_bot,
+                                           const double* h_top, uint32_t* d_keys,
+                                           grace_stream stream);
+grace_status grace_morton_keys63_points_d3(const void* d_points, size_t n, int is_double,
+                                           int elems_per_point, const double* h_bot,
+                                           const double* h_top, uint64_t* d_keys,
+                                           grace_stream stream);
+
 /* ---- stable radix sort: the thrust::sort_by_key(keys, values) call sites
  *      (include/grace/cuda/build_sph.cuh:46,57,70,81; kernels/gen_rays.cuh:483,520,577,615).
  *      Keys ascending, equal keys keep their input order; values (value_bytes per element,
@@ -260,7 +281,11 @@ grace_status grace_trace_status(grace_stream stream);
 
 /* ---- scans ---------------------------------------------------------------------------
  * thrust::exclusive_scan of hit counts (include/grace/cuda/trace_sph.cuh:135-137).
- * In place allowed.  *h_total (optional) receives the grand total: synchronises if given. */
+ * In place allowed.  *h_total (optional) receives the grand total, computed in 64 bits:
+ * synchronises if given.  The offsets themselves wrap modulo 2^32 like the reference's int scan;
+ * a caller that turns them into array positions (trace_sph, trace_with_sentinels_sph) must
+ * refuse a total above INT32_MAX -- the host-side mirrors do, with std::invalid_argument /
+ * ValueError. */
 grace_status grace_scan_exclusive_i32(const int* d_in, size_t n, int* d_out, long long* h_total,
                                       grace_stream stream);
 /* grace::exclusive_segmented_scan (include/grace/cuda/scan.cuh:15-37): per-segment
@@ -289,6 +314,11 @@ grace_status grace_multiply_by_weights_f32(const float* d_unweighted, size_t n,
 grace_status grace_sort_by_distance_f32(float* d_distances, const int* d_ray_offsets,
                                         size_t n_rays, size_t n_hits, int* d_hit_indices,
                                         float* d_hit_data, grace_stream stream);
+
+/* sort_by_distance<double, int, double>: the double outputs of grace_trace_hits_d4. */
+grace_status grace_sort_by_distance_f64(double* d_distances, const int* d_ray_offsets,
+                                        size_t n_rays, size_t n_hits, int* d_hit_indices,
+                                        double* d_hit_data, grace_stream stream);
 
 /* ---- ray inputs (deterministic generators; the reference's cuRAND streams are
  *      device-specific by its own account, include/grace/cuda/kernels/gen_rays.cuh:21-24) */
@@ -343,14 +373,46 @@ grace_status grace_rays_orthographic_projection(int res_x, int res_y, const floa
  * it as float (generic/functors/albvh.h:44-74); deltas[n + 1] floats, +inf at both ends. */
 grace_status grace_deltas_euclid_d4(const double* d_spheres, size_t n, float* d_deltas,
                                     grace_stream stream);
+/* The same with a device_vector<double> of deltas (build_tree<double4> declares
+ * device_vector<Real> deltas, tests/helper/tree.cuh:20-24: the functor's float widened), and
+ * surface_area_deltas_sph<double4> (build_sph.cuh:97-105; generic/functors/albvh.h:84-126 with
+ * AABBSphere narrowing centre -+ radius to float3, generic/functors/aabb.h:9-26). */
+grace_status grace_deltas_euclid_d4_f64(const double* d_spheres, size_t n, double* d_deltas,
+                                        grace_stream stream);
+grace_status grace_deltas_area_d4(const double* d_spheres, size_t n, float* d_deltas,
+                                  grace_stream stream);
+grace_status grace_deltas_area_d4_f64(const double* d_spheres, size_t n, double* d_deltas,
+                                      grace_stream stream);
+/* ALBVH_sph<Real4, DeltaType> (build_sph.cuh:118-124) for the remaining delta types: 64-bit XOR
+ * deltas (morton_keys63_sort_sph -> XOR_deltas_sph -> ALBVH_sph), double deltas, and double4
+ * spheres with XOR deltas.  DeltaComp is thrust::less in all of them (albvh.cuh:1045-1072); a
+ * caller-defined comparator functor cannot cross a C ABI. */
+grace_status grace_albvh_build_f4_u64(const float* d_spheres, size_t n, const uint64_t* d_deltas,
+                                      int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                      size_t* h_n_leaves, grace_stream stream);
+grace_status grace_albvh_build_f4_f64(const float* d_spheres, size_t n, const double* d_deltas,
+                                      int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                      size_t* h_n_leaves, grace_stream stream);
+grace_status grace_albvh_build_d4_f64(const double* d_spheres, size_t n, const double* d_deltas,
+                                      int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                      size_t* h_n_leaves, grace_stream stream);
+grace_status grace_albvh_build_d4_u32(const double* d_spheres, size_t n, const uint32_t* d_deltas,
+                                      int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                      size_t* h_n_leaves, grace_stream stream);
+grace_status grace_albvh_build_d4_u64(const double* d_spheres, size_t n, const uint64_t* d_deltas,
+                                      int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
+                                      size_t* h_n_leaves, grace_stream stream);
 /* ALBVH_sph<double4>: same tree builder; leaf / node boxes are AABBSphere's float3 corners of the
  * double centre -+ radius (generic/functors/aabb.h:9-26).  Same output layout as _f4. */
 grace_status grace_albvh_build_d4(const double* d_spheres, size_t n, const float* d_deltas,
                                   int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
                                   size_t* h_n_leaves, grace_stream stream);
-/* trace_hitcounts_sph / trace_cumulative_sph <double4, double>: sphere_hit and the kernel
- * integral in double, one running double sum per ray in ascending primitive index.  A compact
- * kernel (packets of 64 consecutive rays in caller order), not the tuned float path. */
+/* trace_hitcounts_sph / trace_cumulative_sph / trace_sph pass 2 <double4, (int,) double>
+ * (trace_sph.cuh:57-168): sphere_hit and the kernel integral in double (ray members are float,
+ * generic/intersect.h:9-55), one running double sum per ray in ascending primitive index; per-hit
+ * integrals and distances are double.  Same kernel as the float path (ray coherence order,
+ * cluster tests, culling rounds) walking float records that contain the double spheres; every
+ * surviving candidate is then tested against the caller's double4 record. */
 grace_status grace_trace_hitcounts_d4(const void* d_rays, size_t n_rays, const double* d_spheres,
                                       size_t n_spheres, const int* d_nodes, size_t n_nodes,
                                       const int* d_leaves, const int* d_root, int* d_hit_counts,
@@ -359,6 +421,12 @@ grace_status grace_trace_cumulative_d4(const void* d_rays, size_t n_rays, const 
                                        size_t n_spheres, const int* d_nodes, size_t n_nodes,
                                        const int* d_leaves, const int* d_root, double* d_sums,
                                        grace_stream stream);
+grace_status grace_trace_hits_d4(const void* d_rays, size_t n_rays, const double* d_spheres,
+                                 size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                 const int* d_leaves, const int* d_root, const int* d_ray_offsets,
+                                 int* d_hit_indices, double* d_hit_integrals,
+                                 double* d_hit_distances, grace_stream stream);
+/* Same status word as grace_trace_status (kept for callers of the round-1 interface). */
 grace_status grace_trace_status_d4(grace_stream stream);
 
 #ifdef __cplusplus

@@ -56,6 +56,21 @@ def test_cpp_header_mirror_is_hip_free(tmp_path):
     assert exe2.exists()
 
 
+def test_reference_header_paths_compile_with_hipcc(tmp_path):
+    """The drop-in header set (include/grace/cuda/*.cuh, nodes.h, ray.h, types.h ... over
+    thrust::device_vector) compiles for gfx950 with hipcc: three callers written against the
+    reference's include lines (run on the GPU by tests/test_gpu_dropin.py)."""
+    for name in ("dropin_project_gadget", "dropin_tree_traversal", "dropin_types"):
+        exe = tmp_path / name
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17",
+                               "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "tests", "cpp"),
+                               os.path.join(ROOT, "tests", "cpp", name + ".hip"), "-o", str(exe),
+                               "-L" + os.path.dirname(LIB), "-lgrace_hip",
+                               "-Wl,-rpath," + os.path.dirname(LIB)])
+        assert exe.exists()
+
+
 def test_product_path_does_not_touch_the_oracle():
     """No file of the product (package, headers, C ABI sources) mentions the oracle."""
     bad = []
@@ -64,7 +79,7 @@ def test_product_path_does_not_touch_the_oracle():
             if os.sep + "build" in d or os.sep + "lib" in d or "__pycache__" in d:
                 continue
             for f in files:
-                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".cuh")):
                     txt = open(os.path.join(d, f), errors="ignore").read()
                     if re.search(r"grace_oracle|import oracle|from oracle|go_[a-z]+\(", txt):
                         bad.append(os.path.join(d, f))
