@@ -1591,7 +1591,6 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     GRACE_REQUIRE(n_rays < (size_t(1) << 31), "trace: bad ray count");
     GRACE_REQUIRE(n_nodes >= 1 && n_nodes < (size_t(1) << 30), "trace: bad node count");
     GRACE_REQUIRE(n_spheres > 0 && n_spheres < (size_t(1) << 31), "trace: bad primitive count");
-    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_TRY(ensure_status(stream));
     // Split per-hit trace for small batches (see TraceArgs / hits_plan_kernel): chunk size =
     // a power of two >= one granule giving at most MAX_HIT_CHUNKS chunks.
@@ -1805,6 +1804,7 @@ grace_status grace_trace_hitcounts_f4(const void* d_rays, size_t n_rays, const f
                                       const int* d_leaves, const int* d_root,
                                       int* d_hit_counts, grace_stream stream)
 {
+    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_REQUIRE(d_hit_counts, "trace_hitcounts: null output");
     TraceArgs a = {};
     a.rays = static_cast<const float*>(d_rays);
@@ -1821,6 +1821,7 @@ grace_status grace_trace_cumulative_f4(const void* d_rays, size_t n_rays, const 
                                        const int* d_leaves, const int* d_root,
                                        float* d_cumulated, grace_stream stream)
 {
+    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_REQUIRE(d_cumulated, "trace_cumulative: null output");
     TraceArgs a = {};
     a.rays = static_cast<const float*>(d_rays);
@@ -1839,6 +1840,7 @@ grace_status grace_trace_hits_f4(const void* d_rays, size_t n_rays, const float*
                                  float* d_hit_integrals, float* d_hit_distances,
                                  grace_stream stream)
 {
+    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_REQUIRE(d_ray_offsets && d_hit_indices && d_hit_integrals && d_hit_distances,
                   "trace_hits: null output");
     TraceArgs a = {};
@@ -1859,6 +1861,7 @@ grace_status grace_trace_closest_tri(const void* d_rays, size_t n_rays, const fl
                                      const int* d_leaves, const int* d_root, int* d_closest,
                                      grace_stream stream)
 {
+    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_REQUIRE(d_closest, "trace_closest_tri: null output");
     TraceArgs a = {};
     a.rays = static_cast<const float*>(d_rays);
@@ -1889,6 +1892,7 @@ grace_status grace_trace_hitcounts_d4(const void* d_rays, size_t n_rays, const d
                                       const int* d_leaves, const int* d_root, int* d_hit_counts,
                                       grace_stream stream)
 {
+    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_REQUIRE(d_hit_counts, "trace_hitcounts (double4): null output");
     TraceArgs a = d4_args(d_rays, d_spheres, d_nodes, d_leaves, d_root);
     a.out_counts = d_hit_counts;
@@ -1900,6 +1904,7 @@ grace_status grace_trace_cumulative_d4(const void* d_rays, size_t n_rays, const 
                                        const int* d_leaves, const int* d_root, double* d_sums,
                                        grace_stream stream)
 {
+    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_REQUIRE(d_sums, "trace_cumulative (double4): null output");
     TraceArgs a = d4_args(d_rays, d_spheres, d_nodes, d_leaves, d_root);
     a.out_sums_d = d_sums;
@@ -1912,6 +1917,7 @@ grace_status grace_trace_hits_d4(const void* d_rays, size_t n_rays, const double
                                  int* d_hit_indices, double* d_hit_integrals,
                                  double* d_hit_distances, grace_stream stream)
 {
+    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_REQUIRE(d_ray_offsets && d_hit_indices && d_hit_integrals && d_hit_distances,
                   "trace_hits (double4): null output");
     TraceArgs a = d4_args(d_rays, d_spheres, d_nodes, d_leaves, d_root);
@@ -1929,6 +1935,7 @@ grace_status grace_trace_stats_f4(const void* d_rays, size_t n_rays, const float
                                   const int* d_leaves, const int* d_root,
                                   uint32_t* d_stats4, grace_stream stream)
 {
+    if (n_rays == 0) return GRACE_OK;   // an empty shard of a sharded batch: nothing to trace
     GRACE_REQUIRE(d_stats4, "trace_stats: null output");
     TraceArgs a = {};
     a.rays = static_cast<const float*>(d_rays);

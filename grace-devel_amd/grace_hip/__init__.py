@@ -205,12 +205,11 @@ def ALBVH_sph(spheres, deltas, tree):
     n = len(spheres)
     assert tree.leaves.shape[0] >= n and len(deltas) == n + 1
     n_leaves = C.c_size_t(0)
-    if deltas.dtype == torch.float32:
-        fn = _lib.grace_albvh_build_f4
-    elif deltas.dtype == torch.int32:
-        fn = _lib.grace_albvh_build_f4_u32
-    else:
-        raise ValueError("deltas must be float32 or 32-bit XOR deltas")
+    fn = {torch.float32: _lib.grace_albvh_build_f4, torch.float64: _lib.grace_albvh_build_f4_f64,
+          torch.int32: _lib.grace_albvh_build_f4_u32,
+          torch.int64: _lib.grace_albvh_build_f4_u64}.get(deltas.dtype)
+    if fn is None:
+        raise ValueError("deltas must be float32/float64 or 32/64-bit XOR deltas")
     _check(fn(_ptr(_spheres(spheres)), C.c_size_t(n), _ptr(deltas), C.c_int(tree.max_per_leaf),
               _ptr(tree.nodes), _ptr(tree.leaves), _ptr(tree.root_index), C.byref(n_leaves),
               _stream()))
@@ -307,22 +306,43 @@ def trace_release():
     _check(_lib.grace_trace_release())
 
 
-def trace_hitcounts_sph(rays, spheres, tree, hit_counts):
-    """trace_sph.cuh:58-80."""
+def trace_hitcounts_sph(rays, spheres, tree, hit_counts, check=False):
+    """trace_sph.cuh:58-80.  check=True also reads the traversal's status word (a
+    synchronisation): packet-stack exhaustion then raises instead of waiting for the next
+    trace_status() call."""
     _check_rays(rays)
     assert hit_counts.dtype == torch.int32 and len(hit_counts) == len(rays)
     _check(_lib.grace_trace_hitcounts_f4(*_trace_args(rays, spheres, tree), _ptr(hit_counts),
                                          _stream()))
+    if check:
+        trace_status()
     return hit_counts
 
 
-def trace_cumulative_sph(rays, spheres, tree, cumulated):
-    """trace_sph.cuh:82-110."""
+def trace_cumulative_sph(rays, spheres, tree, cumulated, check=False):
+    """trace_sph.cuh:82-110.  Asynchronous by default (the bench's timed loop relies on it);
+    check=True reads the status word after the launch, as the C++ mirrors do."""
     _check_rays(rays)
     assert cumulated.dtype == torch.float32 and len(cumulated) == len(rays)
     _check(_lib.grace_trace_cumulative_f4(*_trace_args(rays, spheres, tree), _ptr(cumulated),
                                           _stream()))
+    if check:
+        trace_status()
     return cumulated
+
+
+INT32_MAX = 2 ** 31 - 1
+
+
+def _offsets_from_counts(offsets, extra=0):
+    """Hit counts -> exclusive offsets in place; returns the total (64-bit).  int offsets cannot
+    address more than INT32_MAX per-hit slots: ValueError (std::invalid_argument in the C++
+    mirrors) instead of the reference's silent wrap-around."""
+    total = exclusive_scan(offsets, offsets)
+    if total + extra > INT32_MAX:
+        raise ValueError("trace_sph: %d hits (+ %d sentinels) exceed INT32_MAX; the int ray offsets "
+                         "cannot address the per-hit arrays. Trace fewer rays per call." % (total, extra))
+    return total
 
 
 def trace_sph(rays, spheres, tree):
@@ -332,7 +352,7 @@ def trace_sph(rays, spheres, tree):
     n = len(rays)
     offsets = torch.empty(n, dtype=torch.int32, device=rays.device)
     trace_hitcounts_sph(rays, spheres, tree, offsets)
-    total = exclusive_scan(offsets, offsets)
+    total = _offsets_from_counts(offsets)
     idx = torch.empty(total, dtype=torch.int32, device=rays.device)
     integrals = torch.empty(total, dtype=torch.float32, device=rays.device)
     dists = torch.empty(total, dtype=torch.float32, device=rays.device)
@@ -340,6 +360,7 @@ def trace_sph(rays, spheres, tree):
         return offsets, idx, integrals, dists
     _check(_lib.grace_trace_hits_f4(*_trace_args(rays, spheres, tree), _ptr(offsets), _ptr(idx),
                                     _ptr(integrals), _ptr(dists), _stream()))
+    trace_status()
     return offsets, idx, integrals, dists
 
 
@@ -351,7 +372,7 @@ def trace_with_sentinels_sph(rays, spheres, tree, index_sentinel, integral_senti
     n = len(rays)
     offsets = torch.empty(n, dtype=torch.int32, device=rays.device)
     trace_hitcounts_sph(rays, spheres, tree, offsets)
-    total = exclusive_scan(offsets, offsets) + n
+    total = _offsets_from_counts(offsets, extra=n) + n
     _check(_lib.grace_add_iota_i32(_ptr(offsets), C.c_size_t(n), _stream()))
     idx = torch.empty(total, dtype=torch.int32, device=rays.device)
     integrals = torch.empty(total, dtype=torch.float32, device=rays.device)
@@ -362,6 +383,7 @@ def trace_with_sentinels_sph(rays, spheres, tree, index_sentinel, integral_senti
     _check(_lib.grace_fill_u32(_ptr(dists), C.c_size_t(total), C.c_uint32(bits(distance_sentinel)), _stream()))
     _check(_lib.grace_trace_hits_f4(*_trace_args(rays, spheres, tree), _ptr(offsets), _ptr(idx),
                                     _ptr(integrals), _ptr(dists), _stream()))
+    trace_status()
     return offsets, idx, integrals, dists
 
 
@@ -409,6 +431,7 @@ def trace_closest_tri(rays, tris, tree, closest):
                                         C.c_size_t(len(tris)), _ptr(tree.nodes),
                                         C.c_size_t(tree.n_nodes), _ptr(tree.leaves),
                                         _ptr(tree.root_index), _ptr(closest), _stream()))
+    trace_status()
     return closest
 
 
@@ -443,10 +466,11 @@ def exclusive_segmented_scan(segment_offsets, data, results):
 
 def sort_by_distance(hit_distances, ray_offsets, hit_indices, hit_data):
     """sort.cuh:100-131: per-ray sort by distance; indices and data follow."""
-    _check(_lib.grace_sort_by_distance_f32(_ptr(hit_distances), _ptr(ray_offsets),
-                                           C.c_size_t(len(ray_offsets)),
-                                           C.c_size_t(len(hit_distances)), _ptr(hit_indices),
-                                           _ptr(hit_data), _stream()))
+    fn = _lib.grace_sort_by_distance_f64 if hit_distances.dtype == torch.float64 \
+        else _lib.grace_sort_by_distance_f32
+    assert hit_data is None or hit_data.dtype == hit_distances.dtype
+    _check(fn(_ptr(hit_distances), _ptr(ray_offsets), C.c_size_t(len(ray_offsets)),
+              C.c_size_t(len(hit_distances)), _ptr(hit_indices), _ptr(hit_data), _stream()))
 
 
 def weighted_exclusive_segmented_scan(to_sum, weights, weight_map, segment_offsets, out):
@@ -603,6 +627,51 @@ def trace_cumulative_d4(rays, spheres, tree, sums):
     _check(_lib.grace_trace_cumulative_d4(*_trace_args_d4(rays, spheres, tree), _ptr(sums), _stream()))
     _check(_lib.grace_trace_status_d4(_stream()))
     return sums
+
+
+def surface_area_deltas_d4(spheres, deltas):
+    """surface_area_deltas_sph<double4> (build_sph.cuh:97-105); deltas float32 or float64."""
+    _spheres_d4(spheres)
+    fn = _lib.grace_deltas_area_d4_f64 if deltas.dtype == torch.float64 else _lib.grace_deltas_area_d4
+    _check(fn(_ptr(spheres), C.c_size_t(len(spheres)), _ptr(deltas), _stream()))
+    return deltas
+
+
+def euclidean_deltas_d4(spheres, deltas):
+    _spheres_d4(spheres)
+    fn = _lib.grace_deltas_euclid_d4_f64 if deltas.dtype == torch.float64 else _lib.grace_deltas_euclid_d4
+    _check(fn(_ptr(spheres), C.c_size_t(len(spheres)), _ptr(deltas), _stream()))
+    return deltas
+
+
+def ALBVH_d4(spheres, deltas, tree):
+    """ALBVH_sph<double4, DeltaType> for float / double / 32- / 64-bit XOR deltas."""
+    _spheres_d4(spheres)
+    fn = {torch.float32: _lib.grace_albvh_build_d4, torch.float64: _lib.grace_albvh_build_d4_f64,
+          torch.int32: _lib.grace_albvh_build_d4_u32, torch.int64: _lib.grace_albvh_build_d4_u64}[deltas.dtype]
+    n_leaves = C.c_size_t(0)
+    _check(fn(_ptr(spheres), C.c_size_t(len(spheres)), _ptr(deltas), C.c_int(tree.max_per_leaf),
+              _ptr(tree.nodes), _ptr(tree.leaves), _ptr(tree.root_index), C.byref(n_leaves), _stream()))
+    tree.leaves = tree.leaves[: n_leaves.value]
+    tree.nodes = tree.nodes[: n_leaves.value - 1]
+    return tree
+
+
+def trace_sph_d4(rays, spheres, tree):
+    """trace_sph<double4, int, double> (trace_sph.cuh:112-168): (ray_offsets, hit_indices,
+    hit_integrals float64, hit_distances float64)."""
+    n = len(rays)
+    offsets = torch.empty(n, dtype=torch.int32, device=rays.device)
+    trace_hitcounts_d4(rays, spheres, tree, offsets)
+    total = _offsets_from_counts(offsets)
+    idx = torch.empty(total, dtype=torch.int32, device=rays.device)
+    integrals = torch.empty(total, dtype=torch.float64, device=rays.device)
+    dists = torch.empty(total, dtype=torch.float64, device=rays.device)
+    if total:
+        _check(_lib.grace_trace_hits_d4(*_trace_args_d4(rays, spheres, tree), _ptr(offsets), _ptr(idx),
+                                        _ptr(integrals), _ptr(dists), _stream()))
+        trace_status()
+    return offsets, idx, integrals, dists
 
 
 def project_sph(spheres, n_side, max_per_leaf=32):

@@ -20,6 +20,11 @@
 // message and exit()s like GRACE_CUDA_CHECK (include/grace/error.h:40-56).
 #pragma once
 
+#ifdef GRACE_DROPIN_HEADERS_INCLUDED
+#error "grace/grace.h (HIP-free mirror) and the grace/cuda/*.cuh drop-in headers define the same names: include one set only"
+#endif
+#define GRACE_HIP_FREE_MIRROR_INCLUDED 1
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +33,7 @@
 #include <vector>
 
 #include "grace_hip.h"
+#include "grace/ray.h"   // grace::Ray (include/grace/ray.h:5-10)
 
 namespace grace {
 
@@ -46,13 +52,6 @@ enum RaySortType { NoSort, DirectionSort, EndPointSort };
 
 inline float3 make_float3(float x, float y, float z) { float3 v = { x, y, z }; return v; }
 inline float4 make_float4(float x, float y, float z, float w) { float4 v = { x, y, z, w }; return v; }
-
-// include/grace/ray.h:5-10
-struct Ray {
-    float dx, dy, dz;
-    float ox, oy, oz;
-    float length;
-};
 
 namespace detail {
 

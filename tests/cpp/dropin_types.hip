@@ -9,7 +9,9 @@
 // Every traced quantity is compared with a host brute-force loop over grace::sphere_hit in the
 // same precision.  Exit code 0 = PASSED.
 #include "grace/cuda/build_sph.cuh"
+#include "grace/cuda/functors/trace.cuh"
 #include "grace/cuda/gen_rays.cuh"
+#include "grace/cuda/kernels/bintree_trace.cuh"
 #include "grace/cuda/nodes.h"
 #include "grace/cuda/scan.cuh"
 #include "grace/cuda/sort.cuh"
@@ -148,6 +150,43 @@ int main(int argc, char* argv[])
             if (h_idx2[e] != -7 || h_int2[e] != -1.5 || h_dist2[e] != 1e30) ++failures;
         }
         std::cout << "double trace_with_sentinels_sph: " << (failures == before ? "ok" : "FAILED") << std::endl;
+    }
+    // ---- (3) the generic functor trace composed like trace_sph's second pass
+    //          (trace_sph.cuh:143-167: RayEntry_from_array + OnHit_sphere_individual) must
+    //          reproduce the library's per-hit outputs bit for bit
+    {
+        const int before = failures;
+        thrust::device_vector<float4> d_spheres;
+        random_real4(make_float4(0.f, 0.f, 0.f, 0.005f), make_float4(1.f, 1.f, 1.f, 0.03f), N, d_spheres);
+        grace::Tree d_tree(N, 32);
+        build_tree(d_spheres, make_float3(0.f, 0.f, 0.f), make_float3(1.f, 1.f, 1.f), d_tree);
+        thrust::device_vector<int> d_offsets(N_rays);
+        thrust::device_vector<int> d_idx;
+        thrust::device_vector<float> d_int, d_dist;
+        grace::trace_sph(d_rays, d_spheres, d_tree, d_offsets, d_idx, d_int, d_dist);
+
+        thrust::device_vector<int> g_idx(d_idx.size());
+        thrust::device_vector<float> g_int(d_idx.size()), g_dist(d_idx.size());
+        const double* p_table = &(grace::KernelIntegrals<double>::table[0]);
+        thrust::device_vector<double> d_lookup(p_table, p_table + grace::N_table);
+        typedef grace::RayData_sphere<int, float> RayData;
+        grace::trace_texref<RayData>(
+            d_rays, d_spheres, d_tree, sizeof(double) * grace::N_table,
+            grace::InitGlobalToSmem<double>(thrust::raw_pointer_cast(d_lookup.data()), grace::N_table),
+            grace::Intersect_sphere_b2dist(),
+            grace::OnHit_sphere_individual<int, float>(thrust::raw_pointer_cast(g_idx.data()),
+                                                       thrust::raw_pointer_cast(g_int.data()),
+                                                       thrust::raw_pointer_cast(g_dist.data()),
+                                                       grace::N_table),
+            grace::RayEntry_from_array<int>(thrust::raw_pointer_cast(d_offsets.data())),
+            grace::RayExit_null());
+        thrust::host_vector<int> a = d_idx, b = g_idx;
+        thrust::host_vector<float> aw = d_int, bw = g_int, ad = d_dist, bd = g_dist;
+        for (size_t k = 0; k < a.size(); ++k)
+            if (a[k] != b[k] || aw[k] != bw[k] || ad[k] != bd[k]) { ++failures; break; }
+        if (a.size() == 0) ++failures;
+        std::cout << "generic trace_texref + OnHit_sphere_individual == trace_sph (" << a.size()
+                  << " hits): " << (failures == before ? "ok" : "FAILED") << std::endl;
     }
     std::cout << (failures ? "FAILED" : "PASSED") << std::endl;
     return failures ? EXIT_FAILURE : EXIT_SUCCESS;

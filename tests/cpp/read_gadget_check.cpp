@@ -1,5 +1,6 @@
 // Reads a Gadget-2 file with include/grace/read_gadget.h and prints N and column sums so
 // that the pytest harness can compare them with the Python writer's inputs.
+#include "grace/grace.h"
 #include "grace/read_gadget.h"
 
 #include <cstdio>
