@@ -715,6 +715,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     // (plane base + 8 j) serves all of a survivor's reads through immediate offsets.
     // (66 slots: the survivor loop reads up to two slots past the round's last survivor)
     __shared__ float2 s_tile[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 3 : 1][LDS_TILE ? 66 : 1];
+    // *_D4 modes: the round's candidates as doubles, lane-indexed: {x, y, z, w w, 1/w, (1/w)^2}
+    // (the division is done once per candidate by its lane, not once per survivor by the wave).
+    __shared__ double s_tile_d[D4 ? TRACE_BLOCK / 64 : 1][D4 ? 64 : 1][D4 ? 6 : 1];
     const int lane = threadIdx.x & 63;
     constexpr bool SPLITTABLE = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
     static_assert(!SPLIT || SPLITTABLE, "triangle and stats walks do not split");
@@ -1065,10 +1068,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
             const int c_first = r_lo >> 6, c_last = (r_hi - 1) >> 6;
             // Lane j's candidate of cluster c: primitive 64 c + j, clamped into the range (idle
             // lanes then hold a valid candidate and the tests need no control flow).
+            double4 mined_next = make_double4(0., 0., 0., 0.);   // *_D4: the candidate's double4 record
             auto load_cluster = [&](const int c, float4& m4, float2& m2) {
                 const int pj = min(max((c << 6) + lane, r_lo), r_hi - 1);
                 m4 = a.A[pj];
                 if (LDS_TILE && NEED_B) m2 = a.B[pj];
+                if (D4) mined_next = reinterpret_cast<const double4*>(a.spheres_d)[pj];
             };
             // The range's clusters, 64 at a time: lane j decides for cluster cg + j whether ANY ray
             // of the packet can hit ANY of its members (cluster_may_hit); culling rounds then run
@@ -1101,6 +1106,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                     const int pbase = cnext << 6;          // first primitive of this round's cluster
                     const float4 mine = mine_next;
                     const float2 mineb = mineb_next;
+                    const double4 mined = mined_next;
                     const bool more = cmask != 0ull;
                     if (more) {
                         cnext = cg + __builtin_ctzll(cmask);
@@ -1166,6 +1172,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                         if (NEED_B) s_tile[wv][LDS_TILE ? 2 : 0][slot] = mineb;
                     }
                 }
+                if (D4) {
+                    double* t = s_tile_d[wv][lane];
+                    const double ir = 1.f / mined.w;                  // functors/trace.cuh:181
+                    t[0] = mined.x; t[1] = mined.y; t[2] = mined.z;
+                    t[3] = mined.w * mined.w;                         // generic/intersect.h:37
+                    t[4] = ir; t[5] = ir * ir;
+                }
                 const unsigned long long todo = rest;
                 // One survivor: the packet's 64 rays against candidate jj (wave-uniform primitive
                 // index; 0 for the compacted tiles, which do not need it).
@@ -1177,23 +1190,38 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                         // Real = double (functors/trace.cuh:164-186, 196-235: ir = 1.f / w,
                         // b = (N - 1) (sqrt(b2) ir), lerp<double> with the device branch's fma,
                         // integral *= ir ir), on the caller's double4 record (wave-uniform load).
-                        const double* sp = a.spheres_d + 4 * size_t(jj);
-                        const double sx = sp[0], sy = sp[1], sz = sp[2], sw = sp[3];
-                        const double px = sx - ox, py = sy - oy, pz = sz - oz;
-                        const double dot_p = px * rdx + py * rdy + pz * rdz;
-                        const double bx = px - dot_p * rdx, by = py - dot_p * rdy, bz = pz - dot_p * rdz;
-                        const double b2 = bx * bx + by * by + bz * bz;
-                        const bool hit = !(b2 >= sw * sw) && !(dot_p < 0.0f) && !(dot_p >= len);
+                        // (the record staged by the candidate's lane: wave-uniform LDS reads)
+                        const double* sp = s_tile_d[wv][jj - pbase];
+                        const double sx = sp[0], sy = sp[1], sz = sp[2], sw2 = sp[3];
+                        double dot_p, b2;
+                        if (AX >= 0) {
+                            // Axis-aligned packet (d = +-e_AX exactly): sphere_hit collapses under
+                            // IEEE rules exactly as in float -- the two perpendicular products
+                            // with 0 vanish, dot = (s_a - o_a) d_a, b = p - dot d leaves the two
+                            // perpendicular components untouched and cancels the third to 0.
+                            const double sa = AX == 0 ? sx : AX == 1 ? sy : sz;
+                            const double s1 = AX == 0 ? sy : sx;
+                            const double s2 = AX == 2 ? sy : sz;
+                            const double q1 = s1 - double(o1), q2 = s2 - double(o2);
+                            dot_p = (sa - double(oa)) * double(da);
+                            b2 = q1 * q1 + q2 * q2;
+                        } else {
+                            const double px = sx - ox, py = sy - oy, pz = sz - oz;
+                            dot_p = px * rdx + py * rdy + pz * rdz;
+                            const double bx = px - dot_p * rdx, by = py - dot_p * rdy, bz = pz - dot_p * rdz;
+                            b2 = bx * bx + by * by + bz * bz;
+                        }
+                        const bool hit = !(b2 >= sw2) && !(dot_p < 0.0f) && !(dot_p >= len);
                         if (MODE == MODE_COUNT_D4) {
                             count += hit ? 1 : 0;
                         } else if (hit) {
-                            const double ir = 1.f / sw;
+                            const double ir = sp[4];
                             double x = (N_TABLE - 1) * (sqrt(b2) * ir);
                             int x_idx = static_cast<int>(x);
                             if (x_idx >= N_TABLE - 1) { x = double(N_TABLE - 1); x_idx = N_TABLE - 2; }
                             const double2 y = s_lut[x_idx];
                             double integral = __builtin_fma(x - x_idx, y.y, y.x);
-                            integral *= (ir * ir);
+                            integral *= sp[5];
                             if (MODE == MODE_CUM_D4) {
                                 sum_d += integral;
                             } else if (valid) {
