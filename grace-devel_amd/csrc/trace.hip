@@ -651,7 +651,9 @@ __device__ __forceinline__ bool pencil_may_hit(const float4 s, const Pencil& pc)
     return !(d2 > s.w * 1.00001f) || (!(va * inv < cos_limit) && !(out > 0.0f));
 }
 
-template <int AX>
+// FUSED: the fast column-density trace forms b2 as fma(q1, q1, q2 q2) (one instruction fewer per
+// survivor; tolerance parity); its cull must bound THAT expression -- equally monotone.
+template <int AX, bool FUSED = false>
 __device__ __forceinline__ bool axis_beam_may_hit(const float4 s, const Beam& bm)
 {
     constexpr int D1 = AX == 0 ? 1 : 0, D2 = AX == 2 ? 1 : 2;
@@ -659,7 +661,7 @@ __device__ __forceinline__ bool axis_beam_may_hit(const float4 s, const Beam& bm
     const float s2 = AX == 2 ? s.y : s.z;
     const float q1 = s1 - __builtin_amdgcn_fmed3f(s1, bm.olo[D1], bm.ohi[D1]);
     const float q2 = s2 - __builtin_amdgcn_fmed3f(s2, bm.olo[D2], bm.ohi[D2]);
-    const float b2_lo = q1 * q1 + q2 * q2;
+    const float b2_lo = FUSED ? __builtin_fmaf(q1, q1, q2 * q2) : q1 * q1 + q2 * q2;
     return !(b2_lo >= s.w);
 }
 
@@ -1122,7 +1124,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                 // comparisons and combined on the scalar unit: a ballot of a combined boolean
                 // costs two extra vector instructions each.)
                 bool may_hit;
-                if constexpr (AX >= 0) may_hit = axis_beam_may_hit<AX>(mine, beam);
+                if constexpr (AX >= 0) may_hit = axis_beam_may_hit<AX, FAST>(mine, beam);
                 else if constexpr (AX == -2) may_hit = pencil_may_hit(mine, s_pencil[wv]);
                 else may_hit = beam_may_hit(mine, beam);
                 unsigned long long rest = __builtin_amdgcn_ballot_w64(may_hit) & m_mask;
@@ -1249,7 +1251,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                             const float s2 = AX == 2 ? s.y : s.z;
                             const float q1 = s1 - o1, q2 = s2 - o2;
                             dot_p = LEAN ? 0.0f : __builtin_fmaf(sa, da, noda);
-                            b2 = q1 * q1 + q2 * q2;
+                            // (fast integral: fused -- the same value a general packet computes
+                            // for an axis-aligned ray below, so a ray's term does not depend on
+                            // the kind of packet it travels in)
+                            b2 = FAST ? __builtin_fmaf(q1, q1, q2 * q2) : q1 * q1 + q2 * q2;
                         } else {
                             // sphere_hit, include/grace/generic/intersect.h:16-54; s.w = h*h
                             const float px = s.x - ox, py = s.y - oy, pz = s.z - oz;
@@ -1257,7 +1262,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                             const float bx = px - dot_p * dx;
                             const float by = py - dot_p * dy;
                             const float bz = pz - dot_p * dz;
-                            b2 = bx * bx + by * by + bz * bz;
+                            b2 = FAST ? __builtin_fmaf(bx, bx, __builtin_fmaf(by, by, bz * bz))
+                                      : bx * bx + by * by + bz * bz;
                         }
                         if constexpr (FAST && LEAN) {
                             // No hit test at all: a candidate the ray misses has b2 >= h^2, hence a
