@@ -19,8 +19,20 @@ char* Workspace::base_ = nullptr;
 size_t Workspace::capacity_ = 0;
 size_t Workspace::used_ = 0;
 
+// The workspace (like the status word, the prepared scene and the tuning knobs) is
+// process-global: one device, one stream at a time -- the shape of one process per GPU.  A call
+// made with another device current would get pointers into the first device's memory: refuse it.
+static int g_owner_device = -1;
+
 grace_status Workspace::reserve(size_t bytes)
 {
+    int dev = -1;
+    GRACE_TRY_HIP(hipGetDevice(&dev));
+    if (g_owner_device < 0) g_owner_device = dev;
+    if (dev != g_owner_device)
+        return set_error(GRACE_INVALID_ARGUMENT, __FILE__, __LINE__,
+                         "libgrace_hip.so serves one device per process (its workspace lives on the "
+                         "device of the first call): run one process per GPU");
     if (bytes <= capacity_) return GRACE_OK;
     // Grow with headroom so that steady-state calls never allocate.
     size_t want = bytes + bytes / 4 + (size_t(1) << 20);
@@ -54,6 +66,7 @@ grace_status Workspace::release()
     }
     base_ = nullptr;
     capacity_ = used_ = 0;
+    g_owner_device = -1;      // the next call may adopt another device
     return GRACE_OK;
 }
 

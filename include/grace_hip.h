@@ -16,9 +16,14 @@
  *  - Every function returns a grace_status; grace_last_error() describes the last failure
  *    of the calling thread.
  *  - Temporaries come from a grow-only device workspace owned by the library (the
- *    reference allocates and frees thrust temporaries inside every call); it is not
- *    thread-safe, exactly like the reference's global texture references
- *    (include/grace/cuda/kernels/bintree_trace.cuh:37-38).
+ *    reference allocates and frees thrust temporaries inside every call).  Workspace, status
+ *    word, prepared trace scene, timing events and tuning knobs are PROCESS-GLOBAL: one device
+ *    and one stream at a time per process, no concurrent calls from several host threads --
+ *    exactly the reference's constraints (global texture references, default stream:
+ *    include/grace/cuda/kernels/bintree_trace.cuh:37-38) and the shape of one process per GPU.
+ *    A call made with a different device current than the workspace's is refused with
+ *    GRACE_INVALID_ARGUMENT (grace_workspace_release() lets the next call adopt another
+ *    device); the single-process ncclCommInitAll form of multi-GPU use is not supported.
  *  - float4 / int4 / Ray arrays are passed as float* / int* / void* with the reference's
  *    memory layout: sphere = {x, y, z, h}; Ray = {dx,dy,dz,ox,oy,oz,length} (28 B,
  *    include/grace/ray.h:5-10); node = 4 x 16 B, leaf = int4 (include/grace/cuda/nodes.h:22-42).
