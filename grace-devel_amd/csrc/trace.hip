@@ -70,6 +70,7 @@
 // counted per ray by the `stats` instantiation below.
 #include "common.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 using namespace grace_hip;
@@ -132,11 +133,14 @@ struct TraceArgs {
     const int* split_dev;
     // Split per-hit trace (small batches): primitives are cut into n_chunks ranges of
     // 2^chunk_shift consecutive indices.  The counting pass fills chunk_counts[ray][chunk];
-    // the per-hit pass lets wave (packet, part) own chunks part_bounds[packet][part ..
-    // part + 1) and writes a ray's hits of a chunk from chunk_off[ray][chunk] on.
+    // the per-hit pass lets wave w own chunks [wave_map[w].y, wave_map[w].z) of packet
+    // wave_map[w].x -- heavier packets get more waves (hits_assign_kernel) -- and writes a ray's
+    // hits of a chunk from chunk_off[ray][chunk] on.
     int* chunk_counts;
     const int* chunk_off;
-    const int* part_bounds;
+    const int4* wave_map;
+    const int* n_wave_map;
+    bool keep_chunks;       // host only: a hit-count trace whose chunk counts the per-hit trace will reuse
     int chunk_shift, n_chunks;
     int width;              // rays per packet: 64, or 32 / 16 for small batches of the modes that
                             // cannot split a packet (lanes >= width re-trace the packet's last ray)
@@ -749,19 +753,22 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
         }
         __syncthreads();
     }
-    const int packet = wave_id / split, part = wave_id - packet * split;
+    int packet = wave_id / split, part = wave_id - packet * split;
+    // Primitive range owned by this wave (RANGE_SPLIT).
+    int prim_lo = 0, prim_hi = 0x7fffffff;
+    if (RANGE_SPLIT) {
+        if (wave_id >= *a.n_wave_map) return;
+        const int4 wm = a.wave_map[wave_id];
+        packet = wm.x; part = 0;
+        prim_lo = wm.y << a.chunk_shift;
+        prim_hi = wm.z << a.chunk_shift;
+        if (prim_lo >= prim_hi) return;
+    }
     const int first_ray = packet * a.width;
     if (first_ray >= a.n_rays) return;
     // Summation classes owned by this wave: [own_lo, own_hi).
     const int classes_per_part = SUM_CLASSES / split;
     const int own_lo = part * classes_per_part, own_hi = own_lo + classes_per_part;
-    // Primitive range owned by this wave (RANGE_SPLIT).
-    int prim_lo = 0, prim_hi = 0x7fffffff;
-    if (RANGE_SPLIT) {
-        prim_lo = a.part_bounds[packet * (split + 1) + part] << a.chunk_shift;
-        prim_hi = a.part_bounds[packet * (split + 1) + part + 1] << a.chunk_shift;
-        if (prim_lo >= prim_hi) return;
-    }
     auto owns_granule = [&](const int g) {
         if (RANGE_SPLIT) { const int p = g << GRANULE_SHIFT; return p >= prim_lo && p < prim_hi; }
         const int c = g & (SUM_CLASSES - 1);
@@ -912,11 +919,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                       count - count_at_chunk);
         count_at_chunk = count;
     };
-    auto enter_chunk = [&](const int chunk) {
-        leave_chunk();
-        cur_chunk = chunk;
-        if (MODE == MODE_HITS) write_at = a.chunk_off[size_t(ray_index) * a.n_chunks + chunk];
-    };
     // MODE_TRI: RayEntry_tri (tris_trace.cuh:63-73): closest index -1, t_min = length (1 + eps)
     int tri_data = -1;
     float tri_tmin = len * (1.f + 0.000001f);
@@ -953,6 +955,15 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
             }
         }
         staged = 0;
+    };
+    auto enter_chunk = [&](const int chunk) {
+        leave_chunk();
+        cur_chunk = chunk;
+        if (MODE == MODE_HITS) {
+            // the staged hits belong to the chunk being left: out before the cursor moves
+            if (STAGE_HITS && __builtin_amdgcn_ballot_w64(staged != 0) != 0ull) drain_hits();
+            write_at = a.chunk_off[size_t(ray_index) * a.n_chunks + chunk];
+        }
     };
     uint32_t st_nodes = 0, st_leaves = 0, st_tested = 0;
 
@@ -1453,51 +1464,139 @@ __global__ __launch_bounds__(256) void combine_classes_kernel(const float* __res
     out[r] = t[0];
 }
 
-// Plan of the split per-hit trace, one wave per 64-ray packet: each ray's chunk counts become
-// output offsets (exclusive scan along the chunks, starting at the ray's own offset), and the
-// packet's chunks are cut into `split` contiguous ranges of about equal hit totals.
-__global__ __launch_bounds__(64) void hits_plan_kernel(const int* __restrict__ chunk_counts,
-                                                       const int* __restrict__ ray_offsets,
-                                                       const uint32_t* __restrict__ perm, int n_rays,
-                                                       int n_chunks, int split,
-                                                       int* __restrict__ chunk_off,
-                                                       int* __restrict__ part_bounds)
+// Plan of the split per-hit trace.
+// (1) hits_offsets_kernel / hits_plan_kernel: each ray's chunk counts become output offsets
+//     (exclusive scan along the chunks, starting at the ray's own offset); the packet's running
+//     chunk totals are kept (pk_prefix) with its grand total (pk_total).
+// (2) hits_assign_kernel, one workgroup: the W launched waves are dealt to the packets in
+//     proportion to their hit totals -- K_p = 1 + floor((W - P) H_p / H) -- so that waves, not
+//     packets, carry equal work (HEALPix / isotropic bundles: rays along a box diagonal collect
+//     1.7x the hits of rays along an axis; with a fixed K the slowest packet set the kernel time
+//     at 2.5x the mean wave's).
+// (3) hits_bounds_kernel, one wave per packet: its chunks are cut into K_p contiguous ranges of
+//     about equal hit totals; wave first_p + k gets {packet, first chunk, end chunk}.
+// (1a) one wavefront per RAY: the ray's row of chunk counts (contiguous: coalesced) becomes its
+//      row of output offsets.
+__global__ __launch_bounds__(256) void hits_offsets_kernel(const int* __restrict__ chunk_counts,
+                                                           const int* __restrict__ ray_offsets,
+                                                           int n_rays, int n_chunks,
+                                                           int* __restrict__ chunk_off)
 {
-    __shared__ unsigned long long s_total[MAX_HIT_CHUNKS + 1];   // inclusive prefix of the packet's chunk totals
-    const int packet = blockIdx.x, lane = threadIdx.x;
-    const int slot = packet * 64 + lane;
-    const bool valid = slot < n_rays;
-    const int ray = valid ? (perm ? int(perm[slot]) : slot) : 0;
-    int off = valid ? ray_offsets[ray] : 0;
-    unsigned long long run = 0;
-    for (int c = 0; c < n_chunks; ++c) {
-        const int cnt = valid ? chunk_counts[size_t(ray) * n_chunks + c] : 0;
-        if (valid) chunk_off[size_t(ray) * n_chunks + c] = off;
-        off += cnt;
-        unsigned long long t = (unsigned long long)cnt;
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const int* row = chunk_counts + size_t(ray) * n_chunks;
+    int* out = chunk_off + size_t(ray) * n_chunks;
+    int carry = ray_offsets[ray];
+    for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+        const int c = c0 + lane;
+        const int v = c < n_chunks ? row[c] : 0;
+        int incl = v;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-        run += t;
-        if (lane == 0) s_total[c] = run;
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        if (c < n_chunks) out[c] = carry + incl - v;
+        carry += __shfl(incl, 63);
     }
-    __syncthreads();
-    // Boundary k = first chunk whose inclusive prefix reaches k/split of the total.
-    if (lane <= split) {
-        int b;
-        if (lane == 0) b = 0;
-        else if (lane == split) b = n_chunks;
-        else {
-            const unsigned long long want = (run * (unsigned long long)lane + split - 1) / split;
-            int lo = 0, hi = n_chunks - 1;           // smallest c with s_total[c] >= want
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_total[mid] >= want) hi = mid; else lo = mid + 1;
-            }
-            b = lo + 1;                               // chunks [.., lo] belong to the parts before
-            if (b > n_chunks) b = n_chunks;
+}
+
+// (1b) one workgroup per PACKET, one thread per chunk: the packet's hits per chunk (sum over its
+//      64 rays, coalesced along the chunks), their running totals and the grand total.
+__global__ __launch_bounds__(MAX_HIT_CHUNKS) void hits_plan_kernel(const int* __restrict__ chunk_counts,
+                                                                   const uint32_t* __restrict__ perm,
+                                                                   int n_rays, int n_chunks,
+                                                                   uint32_t* __restrict__ pk_prefix,
+                                                                   uint32_t* __restrict__ pk_total)
+{
+    __shared__ uint32_t s_wave[MAX_HIT_CHUNKS / 64];
+    const int packet = blockIdx.x, c = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t t = 0;
+    if (c < n_chunks)
+        for (int r = 0; r < 64; ++r) {
+            const int slot = packet * 64 + r;
+            if (slot >= n_rays) break;
+            const int ray = perm ? int(perm[slot]) : slot;
+            t += uint32_t(chunk_counts[size_t(ray) * n_chunks + c]);
         }
-        part_bounds[packet * (split + 1) + lane] = b;
+    uint32_t incl = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    if (c < n_chunks) pk_prefix[size_t(packet) * n_chunks + c] = before + incl;   // inclusive
+    if (c == n_chunks - 1) pk_total[packet] = before + incl;
+}
+
+__global__ __launch_bounds__(1024) void hits_assign_kernel(const uint32_t* __restrict__ pk_total,
+                                                           int n_packets, int n_waves, int n_chunks,
+                                                           int* __restrict__ pk_first,
+                                                           int* __restrict__ pk_parts,
+                                                           int* __restrict__ n_used)
+{
+    __shared__ unsigned long long s_red[16];
+    __shared__ int s_scan[16];
+    __shared__ int s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long h = 0;
+    for (int p = threadIdx.x; p < n_packets; p += blockDim.x) h += pk_total[p];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if (lane == 0) s_red[wave] = h;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    unsigned long long H = 0;
+    for (int w = 0; w < 16; ++w) H += s_red[w];
+    const unsigned long long pool = (unsigned long long)(n_waves > n_packets ? n_waves - n_packets : 0);
+    for (int base = 0; base < n_packets; base += blockDim.x) {
+        const int p = base + threadIdx.x;
+        int k = 0;
+        if (p < n_packets) {
+            k = 1 + (H ? int(pool * pk_total[p] / H) : 0);
+            if (k > n_chunks) k = n_chunks;
+        }
+        int incl = k;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        int before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_scan[w];
+        if (p < n_packets) { pk_first[p] = before + incl - k; pk_parts[p] = k; }
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) s_carry = before + incl;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) {
+        *n_used = s_carry;
+        *reinterpret_cast<unsigned long long*>(n_used + 2) = H;   // the batch's hit total, for the host
+    }
+}
+
+__global__ __launch_bounds__(64) void hits_bounds_kernel(const uint32_t* __restrict__ pk_prefix,
+                                                         const uint32_t* __restrict__ pk_total,
+                                                         const int* __restrict__ pk_first,
+                                                         const int* __restrict__ pk_parts, int n_chunks,
+                                                         int4* __restrict__ wave_map)
+{
+    const int packet = blockIdx.x, lane = threadIdx.x;
+    const uint32_t* pre = pk_prefix + size_t(packet) * n_chunks;
+    const unsigned long long run = pk_total[packet];
+    const int parts = pk_parts[packet], first = pk_first[packet];
+    // Boundary j = first chunk whose inclusive prefix reaches j / parts of the total.
+    auto boundary = [&](const int j) {
+        if (j <= 0) return 0;
+        if (j >= parts) return n_chunks;
+        const unsigned long long want = (run * (unsigned long long)j + parts - 1) / parts;
+        int lo = 0, hi = n_chunks - 1;           // smallest c with pre[c] >= want
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] >= want) hi = mid; else lo = mid + 1;
+        }
+        return lo + 1 > n_chunks ? n_chunks : lo + 1;   // chunks [.., lo] belong to the parts before
+    };
+    for (int k = lane; k < parts; k += 64)
+        wave_map[first + k] = make_int4(packet, boundary(k), boundary(k + 1), 0);
 }
 
 // How many of the launched waves per packet should work.  The host sizes the launch for an
@@ -1617,6 +1716,23 @@ grace_status scene_prepare(bool tri, const void* prims, size_t n_prims, const in
     return GRACE_OK;
 }
 
+// trace_sph walks twice -- hit counts (for the offsets), then the per-hit pass -- and the split
+// per-hit pass of small batches needs hits per (ray, chunk), a third walk.  The hit-count call
+// made on behalf of trace_sph (grace_trace_hitcounts_keep_f4) records them into this buffer of
+// its own (the workspace is reset by the scan in between); the per-hit call that follows on the
+// same rays and spheres consumes them.
+struct HitsCache {
+    int* chunk_counts = nullptr;
+    size_t capacity = 0;      // ints
+    bool valid = false;
+    const void* rays = nullptr; const void* prims = nullptr;
+    size_t n_rays = 0, n_prims = 0;
+    int n_chunks = 0;
+};
+HitsCache g_hits;
+// split per-hit walk: stage hits in LDS (measurement switch: GRACE_HITS_STAGE=0 -> direct stores)
+const bool g_hits_stage_split = [] { const char* e = std::getenv("GRACE_HITS_STAGE"); return !e || e[0] != '0'; }();
+
 template <int MODE>
 grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n_nodes,
                           hipStream_t stream)
@@ -1638,8 +1754,28 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         else while (hit_split < 8 && hit_packets * hit_split < 16384) hit_split *= 2;
     }
     const bool hits_split = hit_split > 1;
-    int* chunk_counts = nullptr; int* chunk_off = nullptr; int* part_bounds = nullptr;
+    int* chunk_counts = nullptr; int* chunk_off = nullptr;
     int* scratch_counts = nullptr;
+    int4* wave_map = nullptr; int* n_wave_map = nullptr;
+    uint32_t* pk_prefix = nullptr; uint32_t* pk_total = nullptr; int* pk_first = nullptr; int* pk_parts = nullptr;
+    // Would the per-hit trace of this batch use the split path?  (the same rule, for the hit-count
+    // call that is asked to keep its chunk counts)
+    const bool keep_chunks = MODE == MODE_COUNT && a.keep_chunks && g_width <= 0 && hit_packets < 4096
+        && hit_chunks >= 8 && g_split != 1;
+    const bool reuse_chunks = MODE == MODE_HITS && hits_split && g_hits.valid && g_hits.rays == a.rays
+        && g_hits.n_rays == n_rays && g_hits.prims == static_cast<const void*>(a.spheres)
+        && g_hits.n_prims == n_spheres && g_hits.n_chunks == hit_chunks;
+    if (MODE == MODE_HITS || MODE == MODE_COUNT) g_hits.valid = false;   // consumed, or stale from here on
+    if (keep_chunks) {
+        const size_t need = n_rays * size_t(hit_chunks);
+        if (g_hits.capacity < need) {
+            if (g_hits.chunk_counts) { GRACE_TRY_HIP(hipDeviceSynchronize()); GRACE_TRY_HIP(hipFree(g_hits.chunk_counts)); }
+            g_hits.chunk_counts = nullptr; g_hits.capacity = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_hits.chunk_counts), need * sizeof(int));
+            if (e != hipSuccess) return set_error(GRACE_OUT_OF_MEMORY, __FILE__, __LINE__, hipGetErrorString(e));
+            g_hits.capacity = need;
+        }
+    }
     uint32_t* ray_ext = nullptr;
     {
         constexpr bool need_b = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
@@ -1657,7 +1793,9 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                                                + Workspace::aligned(2 * n_clusters * sizeof(float4))
                                                + (MODE == MODE_TRI ? Workspace::aligned(72 * (n_spheres + 4)) : 0))
                                    + (hits_split ? 2 * Workspace::aligned(n_rays * size_t(hit_chunks) * 4)
-                                                   + Workspace::aligned(hit_packets * (hit_split + 1) * 4)
+                                                   + Workspace::aligned(hit_packets * hit_split * sizeof(int4))
+                                                   + Workspace::aligned(hit_packets * size_t(hit_chunks) * 4)
+                                                   + 4 * Workspace::aligned(hit_packets * 4 + 64)
                                                    + Workspace::aligned(n_rays * 4) : 0)
                                    + (MODE == MODE_CUMULATIVE ? Workspace::aligned(n_rays * SUM_CLASSES * 4) : 0)
                                    + (reorder ? 2 * Workspace::aligned(n_rays * 4)
@@ -1683,7 +1821,12 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         if (hits_split) {
             chunk_counts = Workspace::take<int>(n_rays * size_t(hit_chunks));
             chunk_off = Workspace::take<int>(n_rays * size_t(hit_chunks));
-            part_bounds = Workspace::take<int>(hit_packets * (hit_split + 1));
+            wave_map = Workspace::take<int4>(hit_packets * hit_split);
+            pk_prefix = Workspace::take<uint32_t>(hit_packets * size_t(hit_chunks));
+            pk_total = Workspace::take<uint32_t>(hit_packets + 16);
+            pk_first = Workspace::take<int>(hit_packets + 16);
+            pk_parts = Workspace::take<int>(hit_packets + 16);
+            n_wave_map = Workspace::take<int>(16);
             scratch_counts = Workspace::take<int>(n_rays);
         }
         // Subtrees of up to this many primitives are swept -- cluster tests, then culling rounds
@@ -1757,9 +1900,17 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     a.n_chunks = hit_chunks;
     a.chunk_counts = nullptr;
     a.chunk_off = chunk_off;
-    a.part_bounds = part_bounds;
+    a.wave_map = wave_map;
+    a.n_wave_map = n_wave_map;
     if (split > 1 && MODE == MODE_COUNT)
         GRACE_TRY_HIP(hipMemsetAsync(a.out_counts, 0, n_rays * sizeof(int), stream));
+    if (keep_chunks && split > 1) {
+        a.chunk_counts = g_hits.chunk_counts;
+        GRACE_TRY_HIP(hipMemsetAsync(g_hits.chunk_counts, 0, n_rays * size_t(hit_chunks) * 4, stream));
+        g_hits.valid = true;
+        g_hits.rays = a.rays; g_hits.n_rays = n_rays;
+        g_hits.prims = a.spheres; g_hits.n_prims = n_spheres; g_hits.n_chunks = hit_chunks;
+    }
     if (g_timing) {
         if (!g_ev0) {
             GRACE_TRY_HIP(hipEventCreate(&g_ev0));
@@ -1778,21 +1929,44 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         }
     } else if constexpr (MODE == MODE_HITS) {
         if (hits_split) {
-            // 1. hits per (ray, chunk): the counting walk, split by summation class
-            TraceArgs c = a;
-            c.chunk_counts = chunk_counts;
-            c.out_counts = scratch_counts;
-            GRACE_TRY_HIP(hipMemsetAsync(chunk_counts, 0, n_rays * size_t(hit_chunks) * 4, stream));
-            GRACE_TRY_HIP(hipMemsetAsync(scratch_counts, 0, n_rays * 4, stream));
-            trace_kernel<MODE_COUNT, true><<<grid, TRACE_BLOCK, 0, stream>>>(c);
+            // 1. hits per (ray, chunk): the counting walk, split by summation class -- unless the
+            //    hit-count call made for this trace_sph has kept them (grace_trace_hitcounts_keep_f4)
+            const int* counts = g_hits.chunk_counts;
+            if (!reuse_chunks) {
+                TraceArgs c = a;
+                c.chunk_counts = chunk_counts;
+                c.out_counts = scratch_counts;
+                GRACE_TRY_HIP(hipMemsetAsync(chunk_counts, 0, n_rays * size_t(hit_chunks) * 4, stream));
+                GRACE_TRY_HIP(hipMemsetAsync(scratch_counts, 0, n_rays * 4, stream));
+                trace_kernel<MODE_COUNT, true><<<grid, TRACE_BLOCK, 0, stream>>>(c);
+                GRACE_CHECK_LAUNCH();
+                counts = chunk_counts;
+            }
+            // 2. output offsets per (ray, chunk); the launched waves dealt to the packets by hit
+            //    totals; each packet's chunks cut into its waves' ranges
+            hits_offsets_kernel<<<ceil_div(n_rays, 4), 256, 0, stream>>>(counts, a.offsets, int(n_rays),
+                                                                         hit_chunks, chunk_off);
             GRACE_CHECK_LAUNCH();
-            // 2. output offsets per (ray, chunk); each packet's chunks cut into `split` ranges
-            hits_plan_kernel<<<n_packets, 64, 0, stream>>>(chunk_counts, a.offsets, a.perm,
-                                                           int(n_rays), hit_chunks, split, chunk_off,
-                                                           part_bounds);
+            hits_plan_kernel<<<n_packets, MAX_HIT_CHUNKS, 0, stream>>>(counts, a.perm, int(n_rays),
+                                                                       hit_chunks, pk_prefix, pk_total);
             GRACE_CHECK_LAUNCH();
-            // 3. the per-hit walk, wave (packet, part) owning its range of chunks
-            trace_kernel<MODE, true, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+            hits_assign_kernel<<<1, 1024, 0, stream>>>(pk_total, n_packets, n_packets * split, hit_chunks,
+                                                       pk_first, pk_parts, n_wave_map);
+            GRACE_CHECK_LAUNCH();
+            hits_bounds_kernel<<<n_packets, 64, 0, stream>>>(pk_prefix, pk_total, pk_first, pk_parts,
+                                                             hit_chunks, wave_map);
+            GRACE_CHECK_LAUNCH();
+            // 3. the per-hit walk, wave w owning wave_map[w]'s range of chunks
+            //    Heavy packets (output-bandwidth-bound: 10^5 isotropic rays through 10^6 large spheres,
+            //    410 k hits per packet: 18.0 -> 11.0 ms) stage their hits in LDS and store them eight
+            //    per ray at a time; light ones (61 M hits over 768 packets: 3.6 ms direct, 4.5 staged)
+            //    store directly.  The hit total is known on the device only: one 16-byte read-back.
+            unsigned long long h_plan[2] = { 0, 0 };
+            GRACE_TRY_HIP(hipMemcpyAsync(h_plan, n_wave_map, 16, hipMemcpyDeviceToHost, stream));
+            GRACE_TRY_HIP(hipStreamSynchronize(stream));
+            const bool stage = g_hits_stage_split && h_plan[1] / (unsigned long long)n_packets >= 200000ull;
+            if (stage) trace_kernel<MODE, true, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+            else trace_kernel<MODE, true, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
         } else if (n_packets >= 4096) {
             trace_kernel<MODE, false, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
         } else {
@@ -1847,6 +2021,24 @@ grace_status grace_trace_hitcounts_f4(const void* d_rays, size_t n_rays, const f
     a.leaves = reinterpret_cast<const int4*>(d_leaves);
     a.root = d_root;
     a.out_counts = d_hit_counts;
+    return launch_trace<MODE_COUNT>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
+}
+
+grace_status grace_trace_hitcounts_keep_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                           size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                           const int* d_leaves, const int* d_root,
+                                           int* d_hit_counts, grace_stream stream)
+{
+    if (n_rays == 0) return GRACE_OK;
+    GRACE_REQUIRE(d_hit_counts, "trace_hitcounts: null output");
+    TraceArgs a = {};
+    a.rays = static_cast<const float*>(d_rays);
+    a.spheres = reinterpret_cast<const float4*>(d_spheres);
+    a.nodes = reinterpret_cast<const float4*>(d_nodes);
+    a.leaves = reinterpret_cast<const int4*>(d_leaves);
+    a.root = d_root;
+    a.out_counts = d_hit_counts;
+    a.keep_chunks = true;
     return launch_trace<MODE_COUNT>(a, n_rays, n_spheres, n_nodes, as_stream(stream));
 }
 
@@ -2003,7 +2195,15 @@ grace_status grace_trace_prepare_tri(const float* d_tris, size_t n_tris, const i
     return scene_prepare(true, d_tris, n_tris, d_nodes, n_nodes, d_leaves, as_stream(stream));
 }
 
-grace_status grace_trace_release(void) { return scene_release(); }
+grace_status grace_trace_release(void)
+{
+    if (g_hits.chunk_counts) {
+        GRACE_TRY_HIP(hipDeviceSynchronize());
+        GRACE_TRY_HIP(hipFree(g_hits.chunk_counts));
+    }
+    g_hits = HitsCache();
+    return scene_release();
+}
 
 grace_status grace_trace_enable_timing(int enabled)
 {

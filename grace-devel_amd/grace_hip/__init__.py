@@ -306,6 +306,15 @@ def trace_release():
     _check(_lib.grace_trace_release())
 
 
+def _trace_hitcounts_keep(rays, spheres, tree, hit_counts):
+    """The hit-count pass of trace_sph / trace_with_sentinels_sph: for small batches the library
+    keeps the hits per (ray, primitive chunk) for the per-hit pass that follows."""
+    _check_rays(rays)
+    _check(_lib.grace_trace_hitcounts_keep_f4(*_trace_args(rays, spheres, tree), _ptr(hit_counts),
+                                              _stream()))
+    return hit_counts
+
+
 def trace_hitcounts_sph(rays, spheres, tree, hit_counts, check=False):
     """trace_sph.cuh:58-80.  check=True also reads the traversal's status word (a
     synchronisation): packet-stack exhaustion then raises instead of waiting for the next
@@ -351,7 +360,7 @@ def trace_sph(rays, spheres, tree):
     _check_rays(rays)
     n = len(rays)
     offsets = torch.empty(n, dtype=torch.int32, device=rays.device)
-    trace_hitcounts_sph(rays, spheres, tree, offsets)
+    _trace_hitcounts_keep(rays, spheres, tree, offsets)
     total = _offsets_from_counts(offsets)
     idx = torch.empty(total, dtype=torch.int32, device=rays.device)
     integrals = torch.empty(total, dtype=torch.float32, device=rays.device)
@@ -371,7 +380,7 @@ def trace_with_sentinels_sph(rays, spheres, tree, index_sentinel, integral_senti
     _check_rays(rays)
     n = len(rays)
     offsets = torch.empty(n, dtype=torch.int32, device=rays.device)
-    trace_hitcounts_sph(rays, spheres, tree, offsets)
+    _trace_hitcounts_keep(rays, spheres, tree, offsets)
     total = _offsets_from_counts(offsets, extra=n) + n
     _check(_lib.grace_add_iota_i32(_ptr(offsets), C.c_size_t(n), _stream()))
     idx = torch.empty(total, dtype=torch.int32, device=rays.device)

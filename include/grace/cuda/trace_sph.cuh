@@ -76,6 +76,12 @@ inline void hitcounts_dispatch(const Ray* r, size_t nr, const float4* s, size_t 
 inline void hitcounts_dispatch(const Ray* r, size_t nr, const double4* s, size_t n, const TreeArgs& t, int* out)
 { GRACE_STATUS_CHECK(grace_trace_hitcounts_d4(r, nr, reinterpret_cast<const double*>(s), n, t.nodes, t.n_nodes, t.leaves, t.root, out, NULL)); }
 
+// The hit-count pass of trace_sph: the library keeps what the per-hit pass can reuse.
+inline void hitcounts_keep_dispatch(const Ray* r, size_t nr, const float4* s, size_t n, const TreeArgs& t, int* out)
+{ GRACE_STATUS_CHECK(grace_trace_hitcounts_keep_f4(r, nr, reinterpret_cast<const float*>(s), n, t.nodes, t.n_nodes, t.leaves, t.root, out, NULL)); }
+inline void hitcounts_keep_dispatch(const Ray* r, size_t nr, const double4* s, size_t n, const TreeArgs& t, int* out)
+{ hitcounts_dispatch(r, nr, s, n, t, out); }
+
 inline void cumulative_dispatch(const Ray* r, size_t nr, const float4* s, size_t n, const TreeArgs& t, float* out)
 { GRACE_STATUS_CHECK(grace_trace_cumulative_f4(r, nr, reinterpret_cast<const float*>(s), n, t.nodes, t.n_nodes, t.leaves, t.root, out, NULL)); }
 inline void cumulative_dispatch(const Ray* r, size_t nr, const double4* s, size_t n, const TreeArgs& t, double* out)
@@ -161,7 +167,9 @@ GRACE_HOST void trace_sph(
 {
     static_assert(sizeof(IndexType) == sizeof(int), "IndexType must be a 32-bit integer");
     // Initially, d_ray_offsets is actually per-ray *hit counts*.
-    trace_hitcounts_sph(d_rays, d_spheres, d_tree, d_ray_offsets);
+    detail::check_ray_count(d_rays.size());
+    detail::hitcounts_keep_dispatch(detail::raw(d_rays), d_rays.size(), detail::raw(d_spheres),
+                                    d_spheres.size(), detail::tree_args(d_tree), detail::raw(d_ray_offsets));
     const size_t total_hits = detail::counts_to_offsets(d_ray_offsets, 0);
 
     d_hit_integrals.resize(total_hits);
@@ -191,7 +199,9 @@ GRACE_HOST void trace_with_sentinels_sph(
 {
     static_assert(sizeof(IndexType) == sizeof(int), "IndexType must be a 32-bit integer");
     const size_t n_rays = d_rays.size();
-    trace_hitcounts_sph(d_rays, d_spheres, d_tree, d_ray_offsets);
+    detail::check_ray_count(n_rays);
+    detail::hitcounts_keep_dispatch(detail::raw(d_rays), n_rays, detail::raw(d_spheres),
+                                    d_spheres.size(), detail::tree_args(d_tree), detail::raw(d_ray_offsets));
     // Each ray segment in the output arrays ends with a sentinel value marking the end of the
     // ray; increase offsets accordingly (trace_sph.cuh:199-208).
     const size_t allocate_size = detail::counts_to_offsets(d_ray_offsets, n_rays) + n_rays;

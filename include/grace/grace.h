@@ -320,10 +320,17 @@ inline void trace_sph(const device_vector<Ray>& d_rays, const device_vector<floa
                       device_vector<int>& d_hit_indices, device_vector<float>& d_hit_integrals,
                       device_vector<float>& d_hit_distances)
 {
-    trace_hitcounts_sph(d_rays, d_spheres, d_tree, d_ray_offsets);
+    // (the hit-count pass made for a per-hit trace: the library keeps what pass 2 can reuse)
+    detail::check_ray_count(d_rays.size());
+    detail::check(grace_trace_hitcounts_keep_f4(d_rays.data(), d_rays.size(), &d_spheres.data()->x,
+                                                d_spheres.size(), &d_tree.nodes.data()->x,
+                                                d_tree.leaves.size() - 1, &d_tree.leaves.data()->x,
+                                                d_tree.root_index_ptr, d_ray_offsets.data(), nullptr));
     long long total = 0;
     detail::check(grace_scan_exclusive_i32(d_ray_offsets.data(), d_ray_offsets.size(),
                                            d_ray_offsets.data(), &total, nullptr));
+    if (total > 2147483647LL)   // int offsets cannot address more (the reference's int scan would wrap)
+        throw std::invalid_argument("trace_sph: more than INT_MAX hits; trace fewer rays per call.");
     d_hit_integrals.resize(size_t(total));
     d_hit_indices.resize(size_t(total));
     d_hit_distances.resize(size_t(total));
@@ -352,6 +359,9 @@ inline void trace_with_sentinels_sph(const device_vector<Ray>& d_rays,
     long long total = 0;
     detail::check(grace_scan_exclusive_i32(d_ray_offsets.data(), n_rays, d_ray_offsets.data(),
                                            &total, nullptr));
+    if (total + (long long)n_rays > 2147483647LL)
+        throw std::invalid_argument("trace_with_sentinels_sph: more than INT_MAX output slots; "
+                                    "trace fewer rays per call.");
     const size_t allocate_size = size_t(total) + n_rays;
     detail::check(grace_add_iota_i32(d_ray_offsets.data(), n_rays, nullptr));
     d_hit_indices.resize(allocate_size);

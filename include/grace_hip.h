@@ -198,6 +198,15 @@ grace_status grace_trace_hitcounts_f4(const void* d_rays, size_t n_rays, const f
                                       size_t n_spheres, const int* d_nodes, size_t n_nodes,
                                       const int* d_leaves, const int* d_root,
                                       int* d_hit_counts, grace_stream stream);
+/* grace_trace_hitcounts_f4 for a caller that goes on to the per-hit pass (trace_sph,
+ * trace_with_sentinels_sph: trace_sph.cuh:121-141): same output; for small batches it also keeps
+ * the hits per (ray, primitive chunk) in a buffer of the library's, which the next
+ * grace_trace_hits_f4 call on the same rays and spheres consumes instead of walking the tree a
+ * third time.  Any trace call in between drops them. */
+grace_status grace_trace_hitcounts_keep_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
+                                           size_t n_spheres, const int* d_nodes, size_t n_nodes,
+                                           const int* d_leaves, const int* d_root,
+                                           int* d_hit_counts, grace_stream stream);
 grace_status grace_trace_cumulative_f4(const void* d_rays, size_t n_rays, const float* d_spheres,
                                        size_t n_spheres, const int* d_nodes, size_t n_nodes,
                                        const int* d_leaves, const int* d_root,
