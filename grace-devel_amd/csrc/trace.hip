@@ -695,7 +695,30 @@ __device__ __forceinline__ bool cluster_may_hit(const float4 blo, const float4 b
         const float lo2 = AX == 2 ? blo.y : blo.z, hi2 = AX == 2 ? bhi.y : bhi.z;
         return !(lo1 > bm.ohi[D1]) && !(hi1 < bm.olo[D1]) && !(lo2 > bm.ohi[D2]) && !(hi2 < bm.olo[D2]);
     } else if constexpr (AX == -2) {
-        return pencil_may_hit(cluster_sphere(blo, bhi), *pc);
+        // Pencil packet: the bundle lies inside the wedge of its four side planes (outward unit
+        // normals n_k through the common origin) and in front of the origin along the axis.  The
+        // box (already inflated by the members' radii) is wholly outside a plane if even its
+        // innermost corner is: min over the box of n . (p - o) = sum_i min(n_i (lo_i - o_i),
+        // n_i (hi_i - o_i)) > 0; wholly behind if max over the box of a . (p - o) < 0.  Sharper
+        // than the circumscribed sphere for the elongated boxes Morton clusters often have; the
+        // sphere test stays as a second opinion (either may drop the cluster).  Slack: 1e-5 of
+        // the box's distance scale, far above the rounding of these few products.
+        const float lx = blo.x - pc->ox, ly = blo.y - pc->oy, lz = blo.z - pc->oz;
+        const float hx = bhi.x - pc->ox, hy = bhi.y - pc->oy, hz = bhi.z - pc->oz;
+        const float scale = fmaxf(fmaxf(fmaxf(fabsf(lx), fabsf(hx)), fmaxf(fabsf(ly), fabsf(hy))),
+                                  fmaxf(fabsf(lz), fabsf(hz)));
+        const float slack = 1e-5f * scale;
+        float worst = -1.0f;   // largest "innermost corner beyond plane k"
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float m = fminf(pc->nx[k] * lx, pc->nx[k] * hx) + fminf(pc->ny[k] * ly, pc->ny[k] * hy)
+                + fminf(pc->nz[k] * lz, pc->nz[k] * hz);
+            worst = fmaxf(worst, m);
+        }
+        const float front = fmaxf(pc->ax * lx, pc->ax * hx) + fmaxf(pc->ay * ly, pc->ay * hy)
+            + fmaxf(pc->az * lz, pc->az * hz);
+        // (!(a > b) forms: any NaN keeps the cluster)
+        return !(worst > slack) && !(front < -slack) && pencil_may_hit(cluster_sphere(blo, bhi), *pc);
     } else {
         return beam_may_hit(cluster_sphere(blo, bhi), bm, 1.52587890625e-05f /* 2^-16 */);
     }
