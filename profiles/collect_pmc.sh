@@ -12,7 +12,7 @@ mkdir -p $R/gpurun_out/$tag
 sha256sum $R/grace-devel_amd/csrc/trace.hip | cut -d' ' -f1 > $R/gpurun_out/$tag/trace_hip.sha256
 CMD="python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag/stats -o p --output-format csv -- $CMD > $R/gpurun_out/$tag/stats.log 2>&1 || exit 1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_INSTS_BRANCH GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/$tag/insts -o p --output-format csv -- $CMD > $R/gpurun_out/$tag/insts.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace -d $R/gpurun_out/$tag/insts -o p --output-format csv -- $CMD > $R/gpurun_out/$tag/insts.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS --kernel-trace -d $R/gpurun_out/$tag/cycles -o p --output-format csv -- $CMD > $R/gpurun_out/$tag/cycles.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/$tag/fetch -o p --output-format csv -- $CMD > $R/gpurun_out/$tag/fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/$tag/write -o p --output-format csv -- $CMD > $R/gpurun_out/$tag/write.log 2>&1 || exit 1
