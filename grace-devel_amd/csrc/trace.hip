@@ -75,6 +75,17 @@
 
 using namespace grace_hip;
 
+// Diagnostic build (-DGRACE_STAMPS, never the product): s_memtime stamps around the phases of a
+// wave's life, accumulated per wave and summarised on the host after every launch.
+#ifdef GRACE_STAMPS
+#define STAMP_NOW() __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(acc, t0) do { acc += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+__device__ unsigned long long g_stamp_acc[8];
+#else
+#define STAMP_NOW() 0ull
+#define STAMP_ADD(acc, t0) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TRACE_BLOCK = 256;
@@ -489,14 +500,25 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
                                                        const uint32_t* __restrict__ ext12,
                                                        uint32_t* __restrict__ keys)
 {
-    float lo[6], scale[6];
+    float lo[6], scale[6], span[6];
     int nvar = 0;
+    // One scale for the three direction components and one for the three origin components (the
+    // largest extent of each group): cells of the curve are then cubes in ray space whatever the
+    // batch's aspect ratio.  (Scaling every component by its own extent made the packets of a
+    // 1024 x 128-pixel shard 23 x 3-pixel strips instead of 8 x 8 tiles: 9966 surviving
+    // candidates per packet instead of 6687, measured with the stamped diagnostic build.)
+    float span_d = 0.f, span_o = 0.f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         lo[k] = ord2f_u(ext12[k]);
-        const float span = ord2f_u(ext12[6 + k]) - lo[k];
-        const bool varies = span > 0.f && span < INFINITY;
-        scale[k] = varies ? 1.0f / span : 0.f;
+        span[k] = ord2f_u(ext12[6 + k]) - lo[k];
+        const bool varies = span[k] > 0.f && span[k] < INFINITY;
+        if (varies) { if (k < 3) span_d = fmaxf(span_d, span[k]); else span_o = fmaxf(span_o, span[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const bool varies = span[k] > 0.f && span[k] < INFINITY;
+        scale[k] = varies ? 1.0f / (k < 3 ? span_d : span_o) : 0.f;
         nvar += varies ? 1 : 0;
     }
     const int bits = nvar ? min(15, 30 / nvar) : 0;
@@ -509,8 +531,7 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
     // 7.5 ms).  Bundles that cover the whole sphere keep the 3-D curve, which is the better
     // one there (measured: isotropic and HEALPix sources).
     const bool pencil = scale[3] == 0.f && scale[4] == 0.f && scale[5] == 0.f && nvar > 0
-        && !(scale[0] > 0.f && scale[0] < 1.f / 1.5f && scale[1] > 0.f && scale[1] < 1.f / 1.5f
-             && scale[2] > 0.f && scale[2] < 1.f / 1.5f);
+        && !(span[0] > 1.5f && span[1] > 1.5f && span[2] > 1.5f);   // (unit directions: extents <= 2)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float* r = rays + 7 * size_t(i);
         if (pencil) {
@@ -1021,8 +1042,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     };
 
     push(*a.root, ~0ull);
+    unsigned long long st_walk = 0, st_cluster = 0, st_cull = 0, st_surv = 0, st_rounds = 0, st_nsurv = 0;
+    const unsigned long long st_begin = STAMP_NOW();
+    (void)st_walk; (void)st_cluster; (void)st_cull; (void)st_surv; (void)st_rounds; (void)st_nsurv; (void)st_begin;
 
     while (sp >= 0) {
+        const unsigned long long st_t0 = STAMP_NOW(); (void)st_t0;
         int idx;
         unsigned long long alive_mask = ~0ull;
         if (sp < 64) {
@@ -1083,6 +1108,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
             if (MODE == MODE_STATS && alive) { ++st_leaves; st_tested += uint32_t(lf.y); }
 #endif
         }
+        STAMP_ADD(st_walk, st_t0);
         if (sweep) {
             const int2 leaf = make_int2(sweep_first, sweep_count);
             // Touch the next stack entry's cache line now; its pop follows this leaf.
@@ -1115,6 +1141,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
             // of the packet can hit ANY of its members (cluster_may_hit); culling rounds then run
             // over the surviving clusters only, in ascending order.
             for (int cg = c_first; cg <= c_last; cg += 64) {
+                const unsigned long long st_t1 = STAMP_NOW(); (void)st_t1;
                 unsigned long long cmask = 1ull;
                 if (c_last != c_first) {   // (one cluster -- a small leaf -- goes straight to its round)
                     const int cj = min(cg + lane, c_last);
@@ -1130,6 +1157,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                     if (MODE == MODE_STATS) st_leaves += 1;
 #endif
                 }
+                STAMP_ADD(st_cluster, st_t1);
                 if (cmask == 0ull) continue;
                 int cnext = cg + __builtin_ctzll(cmask);
                 cmask &= cmask - 1ull;
@@ -1139,6 +1167,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                 float2 mineb_next = make_float2(0.f, 0.f);
                 load_cluster(cnext, mine_next, mineb_next);
                 for (;;) {
+                    const unsigned long long st_t2 = STAMP_NOW(); (void)st_t2;
                     const int pbase = cnext << 6;          // first primitive of this round's cluster
                     const float4 mine = mine_next;
                     const float2 mineb = mineb_next;
@@ -1216,6 +1245,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                     t[4] = ir; t[5] = ir * ir;
                 }
                 const unsigned long long todo = rest;
+                STAMP_ADD(st_cull, st_t2);
+                const unsigned long long st_t3 = STAMP_NOW(); (void)st_t3;
+#ifdef GRACE_STAMPS
+                st_rounds += 1; st_nsurv += __builtin_popcountll(todo);
+#endif
                 // One survivor: the packet's 64 rays against candidate jj (wave-uniform primitive
                 // index; 0 for the compacted tiles, which do not need it).
                 auto process = [&](auto lean_tag, const float4 s, const float2 sb, const int jj) {
@@ -1396,6 +1430,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                 };
                 if (lean_round) run(std::true_type());
                 else run(std::false_type());
+                STAMP_ADD(st_surv, st_t3);
                 } // !skip_round
                     if (!more) break;
                 } // rounds over the surviving clusters
@@ -1415,6 +1450,15 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
         }
     }
 
+#ifdef GRACE_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_stamp_acc[0], __builtin_amdgcn_s_memtime() - st_begin);
+        atomicAdd(&g_stamp_acc[1], st_walk); atomicAdd(&g_stamp_acc[2], st_cluster);
+        atomicAdd(&g_stamp_acc[3], st_cull); atomicAdd(&g_stamp_acc[4], st_surv);
+        atomicAdd(&g_stamp_acc[5], st_rounds); atomicAdd(&g_stamp_acc[6], st_nsurv);
+        atomicAdd(&g_stamp_acc[7], 1ull);
+    }
+#endif
     if (STAGE_HITS) drain_hits();
     if (CHUNKED && MODE == MODE_COUNT && a.chunk_counts) leave_chunk();
     if ((overflow || junk < 0) && lane == 0) *a.status = GRACE_STACK_OVERFLOW;
@@ -2002,6 +2046,19 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
     }
     GRACE_CHECK_LAUNCH();
+#ifdef GRACE_STAMPS
+    {
+        unsigned long long h[8];
+        GRACE_TRY_HIP(hipDeviceSynchronize());
+        GRACE_TRY_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp_acc), sizeof(h)));
+        const double w = double(h[7] ? h[7] : 1);
+        std::fprintf(stderr, "[stamps] mode %d waves %llu: per wave (s_memtime ticks) total %.0f walk %.0f cluster %.0f "
+                             "cull %.0f survivors %.0f | rounds %.1f survivors %.1f\n", MODE, h[7], h[0] / w,
+                     h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
+        unsigned long long z[8] = {};
+        GRACE_TRY_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), z, sizeof(z)));
+    }
+#endif
     if (MODE == MODE_CUMULATIVE && split > 1) {
         combine_classes_kernel<<<ceil_div(n_rays, 256), 256, 0, stream>>>(a.partial, int(n_rays),
                                                                           split, a.split_dev, a.out_sums);
