@@ -379,7 +379,7 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
     const size_t ws = 3 * Workspace::aligned(n * 4) + Workspace::aligned(scan_ws_count(n) * 4)
         + Workspace::aligned((n + 1) * sizeof(D)) + Workspace::aligned(n * 4)
         + Workspace::aligned(n * 24) + 1024;
-    GRACE_TRY(Workspace::begin(ws));
+    GRACE_TRY(Workspace::begin(ws, stream));
     uint32_t* flags = Workspace::take<uint32_t>(n);
     uint32_t* counts = Workspace::take<uint32_t>(n); // scratch of the pyramids below
     (void)counts;

@@ -45,8 +45,11 @@ inline hipStream_t as_stream(grace_stream s) { return reinterpret_cast<hipStream
 // keeps earlier kernels safe because every entry point runs on one stream at a time).
 class Workspace {
 public:
-    // Makes sure `bytes` are available and resets the bump pointer.
-    static grace_status begin(size_t bytes);
+    // Makes sure `bytes` are available and resets the bump pointer.  `stream` is the stream the
+    // call's kernels run on: a frame opened on another stream than the previous one first waits
+    // (device side) for everything the previous frame's stream has been given, since the two
+    // frames share the same memory.
+    static grace_status begin(size_t bytes, hipStream_t stream);
     template <typename T>
     static T* take(size_t count)
     {

@@ -51,9 +51,20 @@ grace_status Workspace::reserve(size_t bytes)
     return GRACE_OK;
 }
 
-grace_status Workspace::begin(size_t bytes)
+grace_status Workspace::begin(size_t bytes, hipStream_t stream)
 {
     GRACE_TRY(reserve(bytes));
+    // Frames alias: order this one behind the previous frame's stream when the stream changes.
+    static hipStream_t last_stream = nullptr;
+    static bool have_last = false;
+    static hipEvent_t fence = nullptr;
+    if (have_last && stream != last_stream) {
+        if (!fence) GRACE_TRY_HIP(hipEventCreateWithFlags(&fence, hipEventDisableTiming));
+        GRACE_TRY_HIP(hipEventRecord(fence, last_stream));
+        GRACE_TRY_HIP(hipStreamWaitEvent(stream, fence, 0));
+    }
+    last_stream = stream;
+    have_last = true;
     used_ = 0;
     return GRACE_OK;
 }

@@ -344,7 +344,7 @@ static grace_status isotropic_rays(size_t n_rays, float ox, float oy, float oz, 
 {
     GRACE_REQUIRE(n_rays > 0 && d_rays, "isotropic rays: bad argument");
     hipStream_t st = as_stream(stream);
-    GRACE_TRY(Workspace::begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28)));
+    GRACE_TRY(Workspace::begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28), st));
     uint32_t* keys = Workspace::take<uint32_t>(n_rays);
     isotropic_kernel<<<stream_grid(n_rays, 256), 256, 0, st>>>(
         n_rays, ox, oy, oz, length, seed, octant, static_cast<float*>(d_rays), keys);
@@ -380,7 +380,7 @@ grace_status grace_rays_one_to_many(size_t n_rays, float ox, float oy, float oz,
     hipStream_t st = as_stream(stream);
     uint32_t* keys = nullptr;
     if (sort_type != 0) {
-        GRACE_TRY(Workspace::begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28)));
+        GRACE_TRY(Workspace::begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28), st));
         keys = Workspace::take<uint32_t>(n_rays);
     }
     uint32_t* dir_keys = sort_type == 1 ? keys : nullptr;

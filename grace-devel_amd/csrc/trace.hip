@@ -1866,7 +1866,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                                                    + Workspace::aligned(n_rays * 4) : 0)
                                    + (MODE == MODE_CUMULATIVE ? Workspace::aligned(n_rays * SUM_CLASSES * 4) : 0)
                                    + (reorder ? 2 * Workspace::aligned(n_rays * 4)
-                                                + sort_ws_bytes(n_rays, 4, 0) : 0) + 1024));
+                                                + sort_ws_bytes(n_rays, 4, 0) : 0) + 1024, stream));
         if (cached) {
             a.A = g_scene.A;
             a.B = need_b ? (fast_b ? g_scene.B50 : g_scene.B1) : nullptr;

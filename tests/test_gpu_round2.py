@@ -306,3 +306,31 @@ def test_two_rank_sharded_trace_equals_single_rank_image(world, n_side):
     assert all(ok for _, ok, _ in res), res
     if n_side == 8:
         assert res[-1][2] == 0 and res[0][2] == 64      # the trailing ranks' shards are empty
+
+
+def test_calls_on_alternating_streams_share_the_workspace_safely(gh, oracle, cuda):
+    """the library's workspace is one bump-allocated buffer; a frame opened on another
+    stream than the previous one must wait (device side) for the previous frame's kernels.
+    Back-to-back traces of two different ray sets on two torch streams, no host sync between."""
+    n = 300_000
+    s = _dev(oracle.random_real4(n, (0, 0, 0, 0.002), (1, 1, 1, 0.02)), cuda)
+    tree = gh.Tree(n, 32, device=cuda)
+    gh.build_tree(s, tree, (0, 0, 0), (1, 1, 1))
+    ra = gh.uniform_random_rays(32 * 600, (0.5, 0.5, 0.5), 2.0, seed=5, device=cuda)
+    rb = gh.uniform_random_rays(32 * 600, (0.3, 0.6, 0.4), 2.0, seed=6, device=cuda)
+    ref_a = torch.empty(len(ra), dtype=torch.float32, device=cuda); gh.trace_cumulative_sph(ra, s, tree, ref_a)
+    ref_b = torch.empty(len(rb), dtype=torch.float32, device=cuda); gh.trace_cumulative_sph(rb, s, tree, ref_b)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(6):
+        st, rays = ((s1, ra), (s2, rb))[rep % 2]
+        out = torch.empty(len(rays), dtype=torch.float32, device=cuda)
+        with torch.cuda.stream(st):
+            gh.trace_cumulative_sph(rays, s, tree, out)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for rep, out in enumerate(outs):
+        ref = (ref_a, ref_b)[rep % 2]
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), rep
+    gh.trace_status()
