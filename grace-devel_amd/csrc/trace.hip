@@ -70,6 +70,10 @@
 // counted per ray by the `stats` instantiation below.
 #include "common.hpp"
 
+#ifdef GRACE_STAMPS
+#include <algorithm>
+#include <vector>
+#endif
 #include <cstdlib>
 #include <type_traits>
 
@@ -81,6 +85,8 @@ using namespace grace_hip;
 #define STAMP_NOW() __builtin_amdgcn_s_memtime()
 #define STAMP_ADD(acc, t0) do { acc += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 __device__ unsigned long long g_stamp_acc[8];
+__device__ unsigned long long g_stamp_log[1 << 16][4];
+__device__ unsigned int g_stamp_n;
 #else
 #define STAMP_NOW() 0ull
 #define STAMP_ADD(acc, t0) do { } while (0)
@@ -496,6 +502,24 @@ __global__ __launch_bounds__(256) void ray_extents_kernel(const float* __restric
     }
 }
 
+// Position of cell (x, y) of a 2^15 x 2^15 grid along the Hilbert curve (30 bits).  Unlike the
+// Z-order curve it has no jumps: ANY 64 consecutive rays of the sorted order form one connected
+// patch, where a Z-order run that straddles a high-level cell boundary joins two distant patches
+// into one very wide packet (whose wave then outlives the rest of the launch).
+__device__ __forceinline__ uint32_t hilbert2d_15(uint32_t x, uint32_t y)
+{
+    uint32_t d = 0;
+    for (uint32_t s = 1u << 14; s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d = (d << 2) | ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx) { x = 32767u - x; y = 32767u - y; }
+            const uint32_t t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
+
 __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__ rays, int n,
                                                        const uint32_t* __restrict__ ext12,
                                                        uint32_t* __restrict__ keys)
@@ -523,15 +547,16 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
     }
     const int bits = nvar ? min(15, 30 / nvar) : 0;
     const float qmax = float((1 << bits) - 1);
-    // One origin and directions confined to part of the sphere (cameras, cones): scaling each
-    // direction component by its own extent distorts the 3-D curve badly (a camera looking
-    // along z has a tiny, non-linear z extent).  Map the direction to the unit square with the
-    // octahedral parametrisation and order THAT with a 15-bit 2-D curve: a pinhole camera's
-    // pixel grid becomes compact 64-ray patches (closest-hit trace of 10^6 triangles: 13.8 ->
-    // 7.5 ms).  Bundles that cover the whole sphere keep the 3-D curve, which is the better
-    // one there (measured: isotropic and HEALPix sources).
-    const bool pencil = scale[3] == 0.f && scale[4] == 0.f && scale[5] == 0.f && nvar > 0
-        && !(span[0] > 1.5f && span[1] > 1.5f && span[2] > 1.5f);   // (unit directions: extents <= 2)
+    // One origin (cameras, cones, point sources): a 3-D curve over the direction components is a
+    // poor order for points of a 2-D surface (and a camera looking along z has a tiny, non-linear
+    // z extent).  Map the direction to the unit square with the octahedral parametrisation and
+    // order THAT along a 15-bit Hilbert curve: a pinhole camera's pixel grid becomes compact
+    // 64-ray patches (closest-hit trace of 10^6 triangles: 13.8 -> 7.5 ms with the 2-D order),
+    // and because the Hilbert curve never jumps no packet joins two distant patches -- with
+    // Z-order keys 10^5 isotropic rays had packets of up to 6.7x the mean candidate count whose
+    // waves outlived the launch's mean wave 3x (stamped build: surviving candidates per wave
+    // 1977 -> 1576 mean, 13258 -> 3902 max; HEALPix source 1764 -> 1300, 8117 -> 3983).
+    const bool pencil = scale[3] == 0.f && scale[4] == 0.f && scale[5] == 0.f && nvar > 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float* r = rays + 7 * size_t(i);
         if (pencil) {
@@ -545,9 +570,7 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
             // NaN (zero direction) quantises to 0
             const uint32_t qu = uint32_t(fminf(32767.f, fmaxf(0.f, (u * 0.5f + 0.5f) * 32767.f + 0.5f)));
             const uint32_t qv = uint32_t(fminf(32767.f, fmaxf(0.f, (v * 0.5f + 0.5f) * 32767.f + 0.5f)));
-            uint32_t key = 0;
-            for (int b = 14; b >= 0; --b) key = (key << 2) | (((qv >> b) & 1u) << 1) | ((qu >> b) & 1u);
-            keys[i] = key;
+            keys[i] = hilbert2d_15(qu, qv);
             continue;
         }
         uint32_t q[6];
@@ -556,6 +579,18 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
         // the rounding of the scaling (a truncated 1023.9999 would merge two pixel columns and
         // skew every 8x8 tile after it).
         for (int k = 0; k < 6; ++k) q[k] = uint32_t(fminf(qmax, (r[k] - lo[k]) * scale[k] * qmax + 0.5f));
+        if (nvar == 2) {
+            // Two varying co-ordinates (orthographic and plane-parallel batches): the Hilbert curve
+            // again.  A power-of-two pixel grid gives the same 8x8 tiles as the Z-order curve; any
+            // other grid, or jittered origins, gives connected patches where Z-order runs straddle.
+            uint32_t xy[2] = {0, 0};
+            int m = 0;
+#pragma unroll
+            for (int k = 5; k >= 0; --k)
+                if (scale[k] > 0.f) { if (m < 2) xy[m] = q[k]; ++m; }
+            keys[i] = hilbert2d_15(xy[1], xy[0]);
+            continue;
+        }
         uint32_t key = 0;
         for (int b = bits - 1; b >= 0; --b) {
 #pragma unroll
@@ -1457,6 +1492,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
         atomicAdd(&g_stamp_acc[3], st_cull); atomicAdd(&g_stamp_acc[4], st_surv);
         atomicAdd(&g_stamp_acc[5], st_rounds); atomicAdd(&g_stamp_acc[6], st_nsurv);
         atomicAdd(&g_stamp_acc[7], 1ull);
+        {
+            const unsigned slot = atomicAdd(&g_stamp_n, 1u) & 0xffffu;
+            g_stamp_log[slot][0] = st_begin; g_stamp_log[slot][1] = __builtin_amdgcn_s_memtime();
+            g_stamp_log[slot][2] = st_nsurv; g_stamp_log[slot][3] = st_walk;
+        }
     }
 #endif
     if (STAGE_HITS) drain_hits();
@@ -2057,6 +2097,25 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                      h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
         unsigned long long z[8] = {};
         GRACE_TRY_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), z, sizeof(z)));
+        {
+            unsigned nlog = 0;
+            GRACE_TRY_HIP(hipMemcpyFromSymbol(&nlog, HIP_SYMBOL(g_stamp_n), sizeof(nlog)));
+            if (nlog > (1u << 16)) nlog = 1u << 16;
+            std::vector<unsigned long long> lg(size_t(nlog) * 4);
+            if (nlog) GRACE_TRY_HIP(hipMemcpyFromSymbol(lg.data(), HIP_SYMBOL(g_stamp_log), lg.size() * 8));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            std::vector<double> life(nlog), start(nlog), surv(nlog);
+            for (unsigned i = 0; i < nlog; ++i) { t0 = std::min(t0, lg[4 * i]); t1 = std::max(t1, lg[4 * i + 1]); }
+            for (unsigned i = 0; i < nlog; ++i) {
+                life[i] = double(lg[4 * i + 1] - lg[4 * i]); start[i] = double(lg[4 * i] - t0); surv[i] = double(lg[4 * i + 2]);
+            }
+            auto pct = [](std::vector<double> v, double q) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[size_t(q * (v.size() - 1))]; };
+            std::fprintf(stderr, "[stamps] span %.0f | life p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f | start p50 %.0f p90 %.0f max %.0f | nsurv p10 %.0f p50 %.0f p90 %.0f max %.0f\n",
+                         double(t1 - t0), pct(life, .1), pct(life, .5), pct(life, .9), pct(life, .99), pct(life, 1.), pct(start, .5),
+                         pct(start, .9), pct(start, 1.), pct(surv, .1), pct(surv, .5), pct(surv, .9), pct(surv, 1.));
+            unsigned zero = 0;
+            GRACE_TRY_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_n), &zero, sizeof(zero)));
+        }
     }
 #endif
     if (MODE == MODE_CUMULATIVE && split > 1) {
