@@ -81,15 +81,16 @@ def _one(gh, O, dev, rng, seed):
     assert ok, dict(n=n, mpl=mpl, rmax=rmax, kind=str(kind), R=R, exact=exact)
 
 
-@pytest.mark.parametrize("seed", range(1000, 1080))
+@pytest.mark.parametrize("seed", range(1000, 1120))
 def test_random_build_is_the_oracle_tree(gh, oracle, cuda, seed):
-    """Random sizes (2 ... 120 000), max_per_leaf (1 ... 400: both leaf-head code paths),
+    """Random sizes (2 ... 120 000), max_per_leaf (1 ... 400: all three leaf-head code paths and
+    the sparse-table path's boundaries 3/4/5, 31/32/33, 63/64/65),
     duplicate / clustered centres, Euclidean and XOR deltas: nodes, leaves and root identical to
     the oracle's sequential restatement.  (96 298 such builds ran once without a difference.)"""
     O = oracle
     rng = np.random.default_rng(seed)
     n = int(rng.choice([2, 3, 5, 17, 64, 65, 257, 1000, 4097, 30000, 120000]))
-    mpl = int(rng.choice([1, 2, 7, 32, 100, 256, 257, 400]))
+    mpl = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 31, 32, 33, 63, 64, 65, 100, 256, 257, 400]))
     if n <= mpl:
         mpl = max(1, n - 1)
     s = O.random_real4(n, (0, 0, 0, 0), (1, 1, 1, 0.05), first=int(rng.integers(0, 10**6)))
