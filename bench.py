@@ -345,7 +345,10 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_rays * args.steps / elapsed / 1e6
         # Dominant kernel: trace_kernel<cumulative>.  One launch per rank per step.
-        kernel_name = "trace_kernel<1, false, true>"     # MODE_CUMULATIVE, one wave per packet, fast integral
+        # MODE_CUMULATIVE, fast integral; a rank with fewer than 16384 packets of 64 rays runs the
+        # class-split instantiation (several waves per packet, csrc/trace.hip)
+        split_kernel = (per + 63) // 64 < 16384
+        kernel_name = "trace_kernel<1, %s, true>" % ("true" if split_kernel else "false")
         pmc, pmc_note = (None, "PMC passes are collected at N = 1 on the default workload")
         if world == 1 and n == 10_000_000 and args.side == 1024 and args.max_per_leaf == 32:
             pmc, pmc_note = load_pmc(kernel_name)
