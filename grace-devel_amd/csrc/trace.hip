@@ -148,6 +148,7 @@ struct TraceArgs {
     // Class split only: the number of waves per packet that actually work (a power of two <=
     // split, chosen on the device from the batch's coherence); waves beyond it exit at once.
     const int* split_dev;
+    const int* lat_dev;     // which of the LAT = false / true instantiations runs (null: false)
     // Split per-hit trace (small batches): primitives are cut into n_chunks ranges of
     // 2^chunk_shift consecutive indices.  The counting pass fills chunk_counts[ray][chunk];
     // the per-hit pass lets wave w own chunks [wave_map[w].y, wave_map[w].z) of packet
@@ -335,8 +336,10 @@ __global__ __launch_bounds__(256) void cluster_boxes_kernel(const float4* __rest
          c += size_t(gridDim.x) * (blockDim.x / 64)) {
         const size_t i = c * 64 + lane;
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        float r2_min = INFINITY;
         if (i < n) {
             const float4 s = A[i];
+            r2_min = s.w;
             const float r = sqrtf(s.w) * 1.00001f;   // sqrt(fl(h h)) can round below h
             const float ctr[3] = { s.x, s.y, s.z };
 #pragma unroll
@@ -354,8 +357,16 @@ __global__ __launch_bounds__(256) void cluster_boxes_kernel(const float4* __rest
                 hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
             }
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r2_min = fminf(r2_min, __shfl_xor(r2_min, off));
         if (lane == 0) {
-            C[2 * c] = make_float4(lo[0], lo[1], lo[2], 0.f);
+            // the scene's smallest r^2 (positive floats order like their bit patterns); one
+            // float4 past the last cluster record, pre-set to a huge value by scene_fill
+            atomicMin(reinterpret_cast<unsigned int*>(C + 2 * n_clusters), __float_as_uint(r2_min));
+            // .w of the low corner: the smallest r^2 of the members (the origin-lattice cull of
+            // axis-aligned packets looks only at clusters that hold spheres smaller than the
+            // packet's ray spacing)
+            C[2 * c] = make_float4(lo[0], lo[1], lo[2], r2_min);
             C[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
         }
     }
@@ -522,8 +533,27 @@ __device__ __forceinline__ uint32_t hilbert2d_15(uint32_t x, uint32_t y)
 
 __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__ rays, int n,
                                                        const uint32_t* __restrict__ ext12,
-                                                       uint32_t* __restrict__ keys)
+                                                       uint32_t* __restrict__ keys,
+                                                       const float4* __restrict__ scene_min,
+                                                       uint32_t* __restrict__ lat_flag)
 {
+    // choose_lattice: the LAT instantiation runs if all rays share one axis-aligned direction and
+    // the scene holds spheres smaller than the diagonal of the batch's mean ray cell.
+    if (lat_flag && blockIdx.x == 0 && threadIdx.x == 0) {
+        int n_dir = 0;
+        bool one_dir = true;
+        float e1 = 0.f, e2 = 0.f;   // the two largest origin extents
+        for (int k = 0; k < 3; ++k) {
+            const float dl = ord2f_u(ext12[k]), dh = ord2f_u(ext12[6 + k]);
+            one_dir = one_dir && dl == dh;
+            n_dir += dl != 0.f ? 1 : 0;
+            const float e = ord2f_u(ext12[9 + k]) - ord2f_u(ext12[3 + k]);
+            if (e > e1) { e2 = e1; e1 = e; } else if (e > e2) e2 = e;
+        }
+        const float spacing2 = e1 * e2 / float(n);
+        const float r2_min = scene_min->x;
+        *lat_flag = (one_dir && n_dir == 1 && spacing2 > 0.f && r2_min < 2.0f * spacing2) ? 1u : 0u;
+    }
     float lo[6], scale[6], span[6];
     int nvar = 0;
     // One scale for the three direction components and one for the three origin components (the
@@ -579,6 +609,7 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
         // the rounding of the scaling (a truncated 1023.9999 would merge two pixel columns and
         // skew every 8x8 tile after it).
         for (int k = 0; k < 6; ++k) q[k] = uint32_t(fminf(qmax, (r[k] - lo[k]) * scale[k] * qmax + 0.5f));
+#ifndef GRACE_MORTON2D
         if (nvar == 2) {
             // Two varying co-ordinates (orthographic and plane-parallel batches): the Hilbert curve
             // again.  A power-of-two pixel grid gives the same 8x8 tiles as the Z-order curve; any
@@ -591,6 +622,7 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
             keys[i] = hilbert2d_15(xy[1], xy[0]);
             continue;
         }
+#endif
         uint32_t key = 0;
         for (int b = bits - 1; b >= 0; --b) {
 #pragma unroll
@@ -785,10 +817,19 @@ __device__ __forceinline__ bool cluster_may_hit(const float4 blo, const float4 b
 // The class-split instantiations are held to 8 waves per SIMD (<= 64 VGPRs, <= 80 SGPRs: the
 // compiler parks ~28 scalars in VGPR lanes): they exist for small batches, where resident waves
 // are what is scarce (1/8-image shard: K = 4 fits the chip at once, 0.82 -> 0.71 ms).
-template <int MODE, bool SPLIT, bool ALT = false>
+// LAT: the instantiation with the origin-lattice cull (see the packet set-up).  Both variants of
+// a trace are launched; a device flag set from the batch's ray spacing and the scene's smallest
+// sphere (choose_lattice, in ray_keys_kernel) lets exactly one of them run -- the test costs the
+// class-split kernels registers they do not have, and the frame kernel 2 %, so scenes without
+// sub-spacing spheres must not carry it.
+template <int MODE, bool SPLIT, bool ALT = false, bool LAT = false>
 __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) void trace_kernel(const TraceArgs a)
 {
     static_assert(!ALT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS, "no alternative path for this mode");
+    static_assert(!LAT || MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS, "no lattice cull for this mode");
+    if (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS) {
+        if (a.lat_dev ? (*a.lat_dev != 0) != LAT : LAT) return;   // (workgroup-uniform)
+    }
     constexpr bool FAST = ALT && MODE == MODE_CUMULATIVE;
     __shared__ double2 s_lut[FAST ? 1 : N_TABLE];
     __shared__ float2 s_lutf[FAST ? N_TABLE + 1 : 1];
@@ -964,6 +1005,55 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     const float o1 = axis == 0 ? oy : ox;
     const float o2 = axis == 2 ? oy : oz;
     const int treelet = axis >= 0 ? a.treelet_axis : a.treelet;
+    // Origin lattice of an axis-aligned packet.  The beam cull bounds b^2 at the point of the
+    // origin RECTANGLE nearest to the sphere; a sphere smaller than the ray spacing can lie
+    // inside the rectangle and still between the rays -- in the dense cores of clustered SPH
+    // data most do (h << pixel), and every one of them used to cost all 64 lanes a test (10^7
+    // particles, 90 % of them in 50 clumps: 180 863 surviving candidates in the heaviest packet
+    // against 2273 in the median one, whose wave outlived the launch 30x).  If the packet's
+    // origins take at most 8 distinct values in each perpendicular co-ordinate (pixel grids do:
+    // 8 x 8 tiles), the tables of those values give the exact minimum of the rays' own b^2
+    // expression over the lattice {x_i} x {y_j} -- a superset of the rays --: |s - x| rounds
+    // monotonically in the true difference, so the nearest table value minimises the rounded |q|
+    // in each co-ordinate, and b^2 is monotone in both.  No margin, same bits as the ray's test.
+    constexpr bool LATTICE = LAT;
+    __shared__ float s_lat[LATTICE ? TRACE_BLOCK / 64 : 1][2][8];
+    // Spheres with r^2 below this can fall between the rays; 0 = no lattice.  Kept in LDS and
+    // re-read where it is used (once per group of cluster tests): the split kernels have no
+    // scalar register to spare.
+    __shared__ float s_lat_r2[LATTICE ? TRACE_BLOCK / 64 : 1];
+    if (LATTICE && lane == 0) s_lat_r2[threadIdx.x >> 6] = 0.f;
+    if (LATTICE && axis >= 0) {
+        // The distinct values of each co-ordinate, in any order (the nearest one is found by a
+        // plain minimum): take the first lane not yet accounted for, strike every lane that
+        // holds its value, eight times at most.  NaN origins strike nobody: no lattice.
+        bool ok = true;
+        float cell2 = 0.f;
+#pragma unroll
+        for (int dim = 0; dim < 2; ++dim) {
+            const float o = dim ? o2 : o1;
+            unsigned long long todo = ~0ull;
+            int n_val = 0;
+            float v = 0.f, v_lo = INFINITY, v_hi = -INFINITY;
+#pragma unroll 1
+            for (int k = 0; k < 8 && todo != 0ull; ++k) {
+                v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o),
+                                                                        __builtin_ctzll(todo)));
+                v_lo = fminf(v_lo, v); v_hi = fmaxf(v_hi, v);
+                todo &= ~__builtin_amdgcn_ballot_w64(o == v);
+                if (lane == 0) s_lat[threadIdx.x >> 6][dim][k] = v;
+                ++n_val;
+            }
+            ok = ok && todo == 0ull;
+            if (lane == 0)
+                for (int k = n_val; k < 8; ++k) s_lat[threadIdx.x >> 6][dim][k] = v;   // padding repeats
+            // mean spacing (a gate only: it decides which spheres are worth the lattice test)
+            const float gap = n_val > 1 ? (v_hi - v_lo) / float(n_val - 1) : 0.f;
+            cell2 += gap * gap;
+        }
+        // spheres wider than the cell diagonal meet a ray wherever they lie inside the lattice
+        if (lane == 0) s_lat_r2[threadIdx.x >> 6] = ok ? cell2 : 0.f;
+    }
 
     int count = 0;
     // Chunk bookkeeping of the split per-hit trace (see TraceArgs): the counting pass adds each
@@ -1178,10 +1268,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
             for (int cg = c_first; cg <= c_last; cg += 64) {
                 const unsigned long long st_t1 = STAMP_NOW(); (void)st_t1;
                 unsigned long long cmask = 1ull;
+                unsigned long long small_mask = ~0ull;   // clusters with members smaller than the ray spacing
                 if (c_last != c_first) {   // (one cluster -- a small leaf -- goes straight to its round)
                     const int cj = min(cg + lane, c_last);
                     const float4 blo = a.C[2 * size_t(cj)], bhi = a.C[2 * size_t(cj) + 1];
                     const bool c_may = cluster_may_hit<AX>(blo, bhi, beam, &s_pencil[wv]);
+                    if (LATTICE && AX >= 0) small_mask = __builtin_amdgcn_ballot_w64(blo.w < s_lat_r2[wv]);
                     const int n_c = min(64, c_last - cg + 1);
                     cmask = __builtin_amdgcn_ballot_w64(c_may)
                         & (n_c >= 64 ? ~0ull : ((1ull << n_c) - 1ull));
@@ -1226,7 +1318,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                 else if constexpr (AX == -2) may_hit = pencil_may_hit(mine, s_pencil[wv]);
                 else may_hit = beam_may_hit(mine, beam);
                 unsigned long long rest = __builtin_amdgcn_ballot_w64(may_hit) & m_mask;
-                const bool keep = may_hit & (lane >= lo_bit) & (lane < hi_bit);
+                bool keep = may_hit & (lane >= lo_bit) & (lane < hi_bit);
                 // Axis packets: if every kept candidate lies inside every ray's [0, length)
                 // along the axis -- decided per candidate with the same FMA the rays use, which
                 // is monotone in its addend -- the round's survivors skip the two range tests.
@@ -1237,6 +1329,31 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                         __builtin_amdgcn_ballot_w64(__builtin_fmaf(sa, da0, noda_lo) >= 0.0f)
                         & __builtin_amdgcn_ballot_w64(__builtin_fmaf(sa, da0, noda_hi) < len_lo);
                     lean_round = same_sense & ((rest & ~inside) == 0ull);
+                }
+                if constexpr (LATTICE && AX >= 0) {
+                    // Origin-lattice cull (see the packet set-up): only in rounds over clusters that
+                    // hold small spheres, and only if one of them survived the rectangle test.  Kept
+                    // behind the round's main cull so that rounds that never take it (every round of
+                    // a scene without sub-spacing spheres) run the same instruction stream as before
+                    // plus one scalar test.
+                    if (((small_mask >> ((pbase >> 6) - cg)) & 1ull) && rest != 0ull
+                        && __builtin_amdgcn_ballot_w64(keep && mine.w < s_lat_r2[wv]) != 0ull) {
+                        const float s1 = AX == 0 ? mine.y : mine.x;
+                        const float s2 = AX == 2 ? mine.y : mine.z;
+                        float q1 = INFINITY, q2 = INFINITY;
+#pragma unroll 1   // (a rare path: keep its sixteen table values out of the rounds' register budget)
+                        for (int k = 0; k < 8; ++k) {
+                            q1 = fminf(q1, fabsf(s1 - s_lat[wv][0][k]));
+                            q2 = fminf(q2, fabsf(s2 - s_lat[wv][1][k]));
+                        }
+                        // (fminf drops a NaN; a NaN centre must stay -- sphere_hit's negated
+                        // comparisons let it "hit", generic/intersect.h:37-52)
+                        const float nan_if_nan = (s1 + s2) * 0.0f;
+                        const float b2_lo = (FAST ? __builtin_fmaf(q1, q1, q2 * q2) : q1 * q1 + q2 * q2) + nan_if_nan;
+                        keep = keep && !(b2_lo >= mine.w);
+                        rest = __builtin_amdgcn_ballot_w64(keep);
+                        // (lean_round was decided on a superset of the survivors: still valid)
+                    }
                 }
 #ifdef GRACE_PACKET_STATS
                 if (MODE == MODE_STATS) { st_tested += __builtin_popcountll(rest); }
@@ -1542,6 +1659,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
 }
 
 int* g_status = nullptr; // one device int, allocated on first use
+// Measurement hook (grace_trace_last_lattice): the device flag of the last trace launch (lives in
+// the call's workspace frame: valid until the next library call on the device).
+const int* g_last_lat_dev = nullptr;
+hipStream_t g_last_lat_stream = nullptr;
 bool g_timing = false;   // record HIP events around the traversal kernel itself
 hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 bool g_ev_valid = false;
@@ -1787,6 +1908,7 @@ grace_status scene_fill(int kind, const void* prims, size_t n_prims, const float
             GRACE_CHECK_LAUNCH();
         }
     }
+    GRACE_TRY_HIP(hipMemsetAsync(C + 2 * ((n_prims + 63) / 64), 0x7f, sizeof(float4), stream));
     cluster_boxes_kernel<<<stream_grid((n_prims + 63) / 64, 4), 256, 0, stream>>>(A, n_prims, C);
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
@@ -1810,7 +1932,7 @@ grace_status scene_prepare(bool tri, const void* prims, size_t n_prims, const in
     if (st == GRACE_OK && !tri) st = alloc(reinterpret_cast<void**>(&sc.B50), (n_prims + 4) * sizeof(float2));
     if (st == GRACE_OK && tri) st = alloc(reinterpret_cast<void**>(&sc.T64), 72 * (n_prims + 4));
     if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.node_prims), n_nodes * sizeof(int2));
-    if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.C), 2 * ((n_prims + 63) / 64) * sizeof(float4));
+    if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.C), (2 * ((n_prims + 63) / 64) + 1) * sizeof(float4));
     g_scene = sc;   // so that a failure below releases what was allocated
     if (st != GRACE_OK) { scene_release(); return st; }
     st = scene_fill(tri ? 1 : 0, prims, n_prims, reinterpret_cast<const float4*>(d_nodes), n_nodes,
@@ -1897,7 +2019,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         GRACE_TRY(Workspace::begin((cached ? 0 : Workspace::aligned((n_spheres + 4) * sizeof(float4))
                                                + Workspace::aligned((n_spheres + 4) * sizeof(float2))
                                                + Workspace::aligned(n_nodes * sizeof(int2))
-                                               + Workspace::aligned(2 * n_clusters * sizeof(float4))
+                                               + Workspace::aligned((2 * n_clusters + 1) * sizeof(float4))
                                                + (MODE == MODE_TRI ? Workspace::aligned(72 * (n_spheres + 4)) : 0))
                                    + (hits_split ? 2 * Workspace::aligned(n_rays * size_t(hit_chunks) * 4)
                                                    + Workspace::aligned(hit_packets * hit_split * sizeof(int4))
@@ -1918,7 +2040,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             float2* B = need_b ? Workspace::take<float2>(n_spheres + 4) : nullptr;
             double* T64 = (MODE == MODE_TRI) ? Workspace::take<double>(9 * (n_spheres + 4)) : nullptr;
             int2* node_prims = Workspace::take<int2>(n_nodes);
-            float4* C = Workspace::take<float4>(2 * n_clusters);
+            float4* C = Workspace::take<float4>(2 * n_clusters + 1);
             GRACE_TRY(scene_fill(MODE == MODE_TRI ? 1 : D4 ? 2 : 0,
                                  D4 ? static_cast<const void*>(a.spheres_d) : a.spheres, n_spheres, a.nodes, n_nodes, a.leaves, A,
                                  fast_b ? nullptr : B, fast_b ? B : nullptr, T64, node_prims, C, stream));
@@ -1958,8 +2080,10 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             ray_extents_kernel<<<(stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256), 256, 0, stream>>>(a.rays, int(n_rays),
                                                                               ext);
             GRACE_CHECK_LAUNCH();
-            ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(a.rays, int(n_rays), ext,
-                                                                        keys);
+            constexpr bool lat_mode = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
+            ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(
+                a.rays, int(n_rays), ext, keys, a.C + 2 * n_clusters, lat_mode ? ext + 13 : nullptr);
+            if (lat_mode) a.lat_dev = reinterpret_cast<const int*>(ext + 13);
             GRACE_CHECK_LAUNCH();
             // Only the key bits that decide which PACKET a ray joins need sorting: the order of
             // the rays inside a packet is irrelevant (log2(packets) + 2 bits, in whole 8-bit
@@ -2026,13 +2150,23 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         GRACE_TRY_HIP(hipEventRecord(g_ev0, stream));
     }
     const int grid = ceil_div(size_t(n_packets) * split, TRACE_BLOCK / 64);
+    g_last_lat_dev = a.lat_dev; g_last_lat_stream = stream;
+    // Both variants of a kernel with a lattice instantiation (the device flag lets one run).
+    auto both = [&](auto mode_tag, auto split_tag, auto alt_tag, const TraceArgs& args) {
+        constexpr int M = decltype(mode_tag)::value;
+        constexpr bool S = decltype(split_tag)::value, A = decltype(alt_tag)::value;
+        trace_kernel<M, S, A, false><<<grid, TRACE_BLOCK, 0, stream>>>(args);
+        if (args.lat_dev) trace_kernel<M, S, A, true><<<grid, TRACE_BLOCK, 0, stream>>>(args);
+    };
+    using T = std::true_type; using F = std::false_type;
+    using M_ = std::integral_constant<int, MODE>;
     if constexpr (MODE == MODE_CUMULATIVE) {
         if (g_exact_integrals) {
-            if (split > 1) trace_kernel<MODE, true, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
-            else trace_kernel<MODE, false, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+            if (split > 1) both(M_(), T(), F(), a);
+            else both(M_(), F(), F(), a);
         } else {
-            if (split > 1) trace_kernel<MODE, true, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
-            else trace_kernel<MODE, false, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+            if (split > 1) both(M_(), T(), T(), a);
+            else both(M_(), F(), T(), a);
         }
     } else if constexpr (MODE == MODE_HITS) {
         if (hits_split) {
@@ -2045,7 +2179,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                 c.out_counts = scratch_counts;
                 GRACE_TRY_HIP(hipMemsetAsync(chunk_counts, 0, n_rays * size_t(hit_chunks) * 4, stream));
                 GRACE_TRY_HIP(hipMemsetAsync(scratch_counts, 0, n_rays * 4, stream));
-                trace_kernel<MODE_COUNT, true><<<grid, TRACE_BLOCK, 0, stream>>>(c);
+                both(std::integral_constant<int, MODE_COUNT>(), T(), F(), c);
                 GRACE_CHECK_LAUNCH();
                 counts = chunk_counts;
             }
@@ -2072,16 +2206,16 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             GRACE_TRY_HIP(hipMemcpyAsync(h_plan, n_wave_map, 16, hipMemcpyDeviceToHost, stream));
             GRACE_TRY_HIP(hipStreamSynchronize(stream));
             const bool stage = g_hits_stage_split && h_plan[1] / (unsigned long long)n_packets >= 200000ull;
-            if (stage) trace_kernel<MODE, true, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
-            else trace_kernel<MODE, true, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+            if (stage) both(M_(), T(), T(), a);
+            else both(M_(), T(), F(), a);
         } else if (n_packets >= 4096) {
-            trace_kernel<MODE, false, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+            both(M_(), F(), T(), a);
         } else {
-            trace_kernel<MODE, false, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+            both(M_(), F(), F(), a);
         }
     } else if constexpr (MODE == MODE_COUNT) {
-        if (split > 1) trace_kernel<MODE, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
-        else trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        if (split > 1) both(M_(), T(), F(), a);
+        else both(M_(), F(), F(), a);
     } else {
         trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
     }
@@ -2357,6 +2491,17 @@ grace_status grace_trace_last_kernel_ms(float* h_ms)
     GRACE_REQUIRE(g_timing && g_ev_valid, "no timed traversal launch recorded");
     GRACE_TRY_HIP(hipEventSynchronize(g_ev1));
     GRACE_TRY_HIP(hipEventElapsedTime(h_ms, g_ev0, g_ev1));
+    return GRACE_OK;
+}
+
+grace_status grace_trace_last_lattice(int* h_lattice)
+{
+    GRACE_REQUIRE(h_lattice, "null output");
+    *h_lattice = 0;
+    if (g_last_lat_dev) {
+        GRACE_TRY_HIP(hipStreamSynchronize(g_last_lat_stream));
+        GRACE_TRY_HIP(hipMemcpy(h_lattice, g_last_lat_dev, sizeof(int), hipMemcpyDeviceToHost));
+    }
     return GRACE_OK;
 }
 

@@ -260,6 +260,13 @@ def last_kernel_ms():
     return ms.value
 
 
+def last_lattice():
+    """1 if the last trace ran the origin-lattice instantiation (measurement hook)."""
+    v = C.c_int(0)
+    _check(_lib.grace_trace_last_lattice(C.byref(v)))
+    return v.value
+
+
 def set_packet_split(k):
     _check(_lib.grace_trace_set_packet_split(C.c_int(int(k))))
 

@@ -245,6 +245,12 @@ grace_status grace_trace_set_ray_reorder(int enabled);
 grace_status grace_trace_enable_timing(int enabled);
 grace_status grace_trace_last_kernel_ms(float* h_ms);
 
+/* Measurement hook: 1 if the last hit-count / cumulative / per-hit trace ran the kernel
+ * instantiation with the origin-lattice cull (chosen on the device: all rays share one
+ * axis-aligned direction and the scene holds spheres smaller than the mean ray cell), else 0.
+ * Valid until the next library call on the device.  Results never depend on the choice. */
+grace_status grace_trace_last_lattice(int* h_lattice);
+
 /* Waves per 64-ray packet for the hit-count and cumulative traces: 1, 2, 4 or 8 (each wave
  * owns 8/K of the 8 interleaved primitive classes over which the column density is summed), or
  * -1 (default) = as many as it takes to put >= 16384 waves on the chip (>= 4096 if all rays of
