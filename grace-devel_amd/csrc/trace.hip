@@ -1680,10 +1680,12 @@ grace_status ensure_status(hipStream_t stream)
 __global__ __launch_bounds__(256) void combine_classes_kernel(const float* __restrict__ partial,
                                                               int n_rays, int split,
                                                               const int* __restrict__ split_dev,
-                                                              float* __restrict__ out)
+                                                              float* __restrict__ out,
+                                                              const int* __restrict__ run_if = nullptr)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
+    if (run_if && *run_if == 0) return;   // the one-wave-per-packet kernel ran: `out` is final
     if (split_dev) split = *split_dev;
     float t[SUM_CLASSES];
     for (int k = 0; k < split; ++k) t[k] = partial[size_t(r) * split + k];
@@ -1833,11 +1835,13 @@ __global__ __launch_bounds__(64) void hits_bounds_kernel(const uint32_t* __restr
 // wave repeats the upper-tree walk and the cluster tests.  ext12 = the ray
 // extents of the coherence pass (order-preserving uints: minima then maxima of d, o).
 __global__ void choose_split_kernel(const uint32_t* __restrict__ ext12, int n_packets, int launched,
-                                    int* __restrict__ split_dev)
+                                    int* __restrict__ split_dev, const uint32_t* __restrict__ lat_flag)
 {
     const bool one_direction = ext12[0] == ext12[6] && ext12[1] == ext12[7] && ext12[2] == ext12[8];
     int k = launched;
-    if (one_direction) {
+    // (a scene with spheres smaller than the ray spacing has packets of very unequal weight: it
+    // keeps every launched wave -- see lat_split in launch_trace)
+    if (one_direction && !(lat_flag && *lat_flag != 0u)) {
         // Measured on 1/8 ... 1/1 shards of the 1024^2 frame (2048 ... 16384 packets): best K =
         // 4, 2, 2, 1.  The split kernels run 8 waves per SIMD: 8192 waves fill the chip once;
         // from 6144 packets on a second wave per packet still pays (16384 waves).
@@ -1849,6 +1853,13 @@ __global__ void choose_split_kernel(const uint32_t* __restrict__ ext12, int n_pa
 }
 
 int g_split = -1; // waves per packet; -1: automatic
+// waves per packet for big batches of scenes with sub-spacing spheres (measurement switch:
+// GRACE_LAT_SPLIT=0 keeps one wave per packet; 2, 4 (default), 8)
+const int g_lat_split = [] {
+    const char* e = std::getenv("GRACE_LAT_SPLIT");
+    const int k = e ? std::atoi(e) : 4;
+    return (k == 0 || k == 2 || k == 4 || k == 8) ? k : 4;
+}();
 int g_width = -1; // rays per packet of the per-hit / triangle traces; -1: automatic
 bool g_exact_integrals = false; // column-density trace: bit-reproducible per-hit arithmetic
 
@@ -2122,7 +2133,8 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     a.split_dev = nullptr;
     if ((MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) && split > 1 && g_split <= 0 && ray_ext) {
         int* split_dev = reinterpret_cast<int*>(ray_ext + 12);
-        choose_split_kernel<<<1, 1, 0, stream>>>(ray_ext, n_packets, split, split_dev);
+        choose_split_kernel<<<1, 1, 0, stream>>>(ray_ext, n_packets, split, split_dev,
+                                                 a.lat_dev ? ray_ext + 13 : nullptr);
         GRACE_CHECK_LAUNCH();
         a.split_dev = split_dev;
     }
@@ -2160,12 +2172,41 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     };
     using T = std::true_type; using F = std::false_type;
     using M_ = std::integral_constant<int, MODE>;
+    // A batch of >= 16384 packets runs one wave per packet -- unless the device flag says the scene
+    // holds spheres smaller than the ray spacing (clustered SPH data: dense cores).  Such scenes
+    // have packets dozens of times heavier than the median (10^7 particles, 90 % of them in 50
+    // clumps: with the lattice cull the heaviest of 16384 waves still lived 14x the mean and set
+    // the kernel time), so the lattice instantiation of these batches is the class-split kernel
+    // with four waves per packet: the heaviest packets' work is spread over four SIMDs (measured
+    // on two clustered scenes: K = 2 / 4 / 8 -> 3.62 / 3.47 / 4.24 ms and 4.24 / 3.42 / 3.71 ms;
+    // one wave: 4.66 and 6.78 ms).  Same class sums, same bits.
+    const bool lat_split = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) && split == 1 && a.lat_dev && width == 64
+        && g_lat_split > 0 && g_split <= 0;   // (an explicit grace_trace_set_packet_split is obeyed)
+    auto one_or_split = [&](auto alt_tag) -> grace_status {
+        constexpr bool A = decltype(alt_tag)::value;
+        constexpr int M = (MODE == MODE_COUNT) ? MODE_COUNT : MODE_CUMULATIVE;
+        if (MODE == MODE_COUNT) GRACE_TRY_HIP(hipMemsetAsync(a.out_counts, 0, n_rays * sizeof(int), stream));
+        trace_kernel<M, false, A, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        GRACE_CHECK_LAUNCH();
+        TraceArgs a8 = a;
+        a8.split = g_lat_split; a8.split_dev = nullptr;
+        trace_kernel<M, true, A, true><<<ceil_div(size_t(n_packets) * g_lat_split, TRACE_BLOCK / 64), TRACE_BLOCK, 0, stream>>>(a8);
+        GRACE_CHECK_LAUNCH();
+        if (MODE == MODE_CUMULATIVE) {
+            combine_classes_kernel<<<ceil_div(n_rays, 256), 256, 0, stream>>>(a.partial, int(n_rays), g_lat_split,
+                                                                              nullptr, a.out_sums, a.lat_dev);
+            GRACE_CHECK_LAUNCH();
+        }
+        return GRACE_OK;
+    };
     if constexpr (MODE == MODE_CUMULATIVE) {
         if (g_exact_integrals) {
             if (split > 1) both(M_(), T(), F(), a);
+            else if (lat_split) GRACE_TRY(one_or_split(F()));
             else both(M_(), F(), F(), a);
         } else {
             if (split > 1) both(M_(), T(), T(), a);
+            else if (lat_split) GRACE_TRY(one_or_split(T()));
             else both(M_(), F(), T(), a);
         }
     } else if constexpr (MODE == MODE_HITS) {
@@ -2215,6 +2256,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         }
     } else if constexpr (MODE == MODE_COUNT) {
         if (split > 1) both(M_(), T(), F(), a);
+        else if (lat_split) GRACE_TRY(one_or_split(F()));
         else both(M_(), F(), F(), a);
     } else {
         trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);

@@ -235,6 +235,54 @@ def test_sub_pixel_spheres_between_the_rays_of_a_pixel_grid(gh, oracle, cuda, ax
                 gh.trace_release()
 
 
+def test_clustered_scene_full_frame_splits_packets_and_stays_bit_identical(gh, oracle, cuda):
+    """1024^2 orthographic rays (16384 packets: normally one wave each) through a clustered scene
+    with sub-pixel spheres: the device flag sends the batch to the lattice instantiation with four
+    waves per packet.  Hit counts and bit-exact column densities must equal the one-wave-per-packet
+    trace (grace_trace_set_packet_split(1)) bit for bit, and brute force on a subset of the rays."""
+    g = torch.Generator(device=cuda); g.manual_seed(5)
+    n, nb = 1_200_000, 300_000
+    pos = torch.rand((nb, 3), generator=g, device=cuda)
+    dens = torch.full((nb,), float(nb), device=cuda)
+    n_clumps = 20; nc = n - nb
+    centres = torch.rand((n_clumps, 3), generator=g, device=cuda) * 0.8 + 0.1
+    sig = 10 ** (torch.rand(n_clumps, generator=g, device=cuda) * 1.2 - 2.8)
+    which = torch.randint(0, n_clumps, (nc,), generator=g, device=cuda)
+    p = centres[which] + torch.randn((nc, 3), generator=g, device=cuda) * sig[which, None]
+    r2 = ((p - centres[which]) ** 2).sum(1) / sig[which] ** 2
+    d = (nc / n_clumps) * torch.exp(-0.5 * r2) / ((2 * math.pi) ** 1.5 * sig[which] ** 3) + nb
+    pos = torch.cat([pos, p.clamp(0, 1)]); dens = torch.cat([dens, d])
+    h = (3 * 48 / (4 * math.pi * dens)) ** (1 / 3)
+    s = torch.cat([pos, h[:, None]], 1).float().contiguous()
+    assert float(h.min()) < 0.5 / 1024                            # below the pixel spacing
+    lo, hi = gh.min_max_vec4(s); lo[3] = hi[3] = 0
+    tree = gh.Tree(n, 32, device=cuda); gh.build_tree(s, tree, lo[:3], hi[:3])
+    rays, _ = gh.orthogonal_rays_z(1024, lo, hi, device=cuda)
+    R = len(rays)
+    out = {}
+    for K in (-1, 1):
+        gh.set_packet_split(K)
+        try:
+            hc = torch.empty(R, dtype=torch.int32, device=cuda); cu = torch.empty(R, dtype=torch.float32, device=cuda)
+            gh.trace_hitcounts_sph(rays, s, tree, hc, check=True)
+            assert gh.last_lattice() == 1
+            gh.set_exact_integrals(True)
+            gh.trace_cumulative_sph(rays, s, tree, cu, check=True)
+            gh.set_exact_integrals(False)
+            cf = torch.empty(R, dtype=torch.float32, device=cuda)
+            gh.trace_cumulative_sph(rays, s, tree, cf, check=True)
+            out[K] = (hc, cu, cf)
+        finally:
+            gh.set_packet_split(-1); gh.set_exact_integrals(False)
+    for a, b in zip(out[-1], out[1]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    sub = torch.arange(0, R, R // 192, device=cuda)[:192]
+    rh = rays[sub].cpu().numpy(); sh = s.cpu().numpy()
+    assert np.array_equal(out[-1][0][sub].cpu().numpy(), oracle.brute_hitcounts(rh, sh))
+    c32, _ = oracle.brute_cumulative(rh, sh)
+    assert np.array_equal(out[-1][1][sub].cpu().numpy().view(np.uint32), c32.view(np.uint32))
+
+
 # ---- remaining instantiations -----------------------------------------------------------------
 def test_albvh_from_64bit_xor_deltas_and_double_deltas(gh, oracle, cuda):
     """morton_keys63_sort_sph -> XOR_deltas_sph<uinteger64> -> ALBVH_sph<float4, uinteger64>
