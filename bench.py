@@ -348,7 +348,9 @@ def main():
         # MODE_CUMULATIVE, fast integral; a rank with fewer than 16384 packets of 64 rays runs the
         # class-split instantiation (several waves per packet, csrc/trace.hip)
         split_kernel = (per + 63) // 64 < 16384
-        kernel_name = "trace_kernel<1, %s, true>" % ("true" if split_kernel else "false")
+        # (last parameter: the lattice instantiation, for scenes with spheres smaller than the ray
+        # spacing -- not this one)
+        kernel_name = "trace_kernel<1, %s, true, false>" % ("true" if split_kernel else "false")
         pmc, pmc_note = (None, "PMC passes are collected at N = 1 on the default workload")
         if world == 1 and n == 10_000_000 and args.side == 1024 and args.max_per_leaf == 32:
             pmc, pmc_note = load_pmc(kernel_name)
