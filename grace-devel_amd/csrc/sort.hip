@@ -237,6 +237,13 @@ grace_status sort_pairs(Key* d_keys, void* d_values, size_t n, int value_bytes, 
     Key* k_out = keys_alt;
     uint32_t* i_in = idx_a;
     uint32_t* i_out = idx_b;
+    // A caller that wants the permutation gets it written by the last pass itself (its buffer
+    // takes part in the ping-pong so that the final output lands in it): no copy afterwards.
+    const int n_passes = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
+    if (d_perm_out) {
+        if (n_passes % 2) i_out = d_perm_out;     // passes 1, 3, ... write i_out's first value
+        else i_in = d_perm_out;                   // passes 2, 4, ... write what starts as i_in
+    }
     bool first = true;
     for (int shift = begin_bit; shift < end_bit; shift += RADIX_BITS) {
         const int bits = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
@@ -266,7 +273,7 @@ grace_status sort_pairs(Key* d_keys, void* d_values, size_t n, int value_bytes, 
                                      hipMemcpyDeviceToDevice, stream));
         GRACE_TRY(gather_payload(tmp, i_in, d_values, n, value_bytes, stream));
     }
-    if (d_perm_out)
+    if (d_perm_out && i_in != d_perm_out)        // (cannot happen: see the ping-pong set-up)
         GRACE_TRY_HIP(hipMemcpyAsync(d_perm_out, i_in, n * 4, hipMemcpyDeviceToDevice, stream));
     return GRACE_OK;
 }

@@ -56,7 +56,7 @@
 //     work for any beam -- with NO change of the result: each wave reduces its classes, a
 //     tiny kernel finishes the tree.  K is the smallest power of two that puts >= 16384 waves
 //     in flight; for batches of one direction (light packets) a device-side choice lowers it
-//     to what reaches 4096 waves (choose_split_kernel).  A wave keeps its class accumulators in LDS (2 KiB) and switches at granule
+//     to what reaches 4096 waves (choose_split).  A wave keeps its class accumulators in LDS (2 KiB) and switches at granule
 //     boundaries, once per culling round at most.  Hit counts split the same way (integers);
 //   * per-hit outputs (ordered per ray): large batches stage hits per lane in LDS and drain
 //     them eight entries per ray; small batches split a packet over K waves by contiguous
@@ -513,6 +513,28 @@ __global__ __launch_bounds__(256) void ray_extents_kernel(const float* __restric
     }
 }
 
+// How many of the launched waves per packet should work.  The host sizes the launch for an
+// incoherent batch (whose packets are heavy: >= 16384 waves in flight pay off); a batch whose
+// rays all share one direction (orthographic shards) has light packets, for which every extra
+// wave repeats the upper-tree walk and the cluster tests.  ext12 = the ray
+// extents of the coherence pass (order-preserving uints: minima then maxima of d, o).
+__device__ int choose_split(const uint32_t* __restrict__ ext12, int n_packets, int launched, bool lattice)
+{
+    const bool one_direction = ext12[0] == ext12[6] && ext12[1] == ext12[7] && ext12[2] == ext12[8];
+    int k = launched;
+    // (a scene with spheres smaller than the ray spacing has packets of very unequal weight: it
+    // keeps every launched wave -- see lat_split in launch_trace)
+    if (one_direction && !lattice) {
+        // Measured on 1/8 ... 1/1 shards of the 1024^2 frame (2048 ... 16384 packets): best K =
+        // 4, 2, 2, 1.  The split kernels run 8 waves per SIMD: 8192 waves fill the chip once;
+        // from 6144 packets on a second wave per packet still pays (16384 waves).
+        k = 1;
+        while (k < launched && n_packets * k < 8192) k *= 2;
+        if (k < launched && n_packets >= 6144 && n_packets * k < 16384) k *= 2;
+    }
+    return k;
+}
+
 // Position of cell (x, y) of a 2^15 x 2^15 grid along the Hilbert curve (30 bits).  Unlike the
 // Z-order curve it has no jumps: ANY 64 consecutive rays of the sorted order form one connected
 // patch, where a Z-order run that straddles a high-level cell boundary joins two distant patches
@@ -535,7 +557,9 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
                                                        const uint32_t* __restrict__ ext12,
                                                        uint32_t* __restrict__ keys,
                                                        const float4* __restrict__ scene_min,
-                                                       uint32_t* __restrict__ lat_flag)
+                                                       uint32_t* __restrict__ lat_flag,
+                                                       int split_packets, int split_launched,
+                                                       int* __restrict__ split_dev)
 {
     // choose_lattice: the LAT instantiation runs if all rays share one axis-aligned direction and
     // the scene holds spheres smaller than the diagonal of the batch's mean ray cell.
@@ -554,6 +578,10 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
         const float r2_min = scene_min->x;
         *lat_flag = (one_dir && n_dir == 1 && spacing2 > 0.f && r2_min < 2.0f * spacing2) ? 1u : 0u;
     }
+    // choose_split (class-split hit-count / cumulative launches): how many of the launched waves
+    // per packet work
+    if (split_dev && blockIdx.x == 0 && threadIdx.x == 0)
+        *split_dev = choose_split(ext12, split_packets, split_launched, lat_flag ? *lat_flag != 0u : false);
     float lo[6], scale[6], span[6];
     int nvar = 0;
     // One scale for the three direction components and one for the three origin components (the
@@ -850,7 +878,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     // Hit counts and column densities split a packet by summation class (interleaved granules);
     // the per-hit trace, whose output is ordered, by contiguous chunk ranges chosen per packet.
     constexpr bool RANGE_SPLIT = SPLIT && MODE == MODE_HITS;
-    // Waves per packet: as launched, or fewer when the device-side choice (choose_split_kernel)
+    // Waves per packet: as launched, or fewer when the device-side choice (choose_split)
     // says so.  The working waves are packed into the first workgroups -- surplus workgroups exit
     // whole, before touching LDS, so that they do not hold resources of the working ones.
     const int split = !SPLIT ? 1 : (!RANGE_SPLIT && a.split_dev) ? *a.split_dev : a.split;
@@ -1829,29 +1857,6 @@ __global__ __launch_bounds__(64) void hits_bounds_kernel(const uint32_t* __restr
         wave_map[first + k] = make_int4(packet, boundary(k), boundary(k + 1), 0);
 }
 
-// How many of the launched waves per packet should work.  The host sizes the launch for an
-// incoherent batch (whose packets are heavy: >= 16384 waves in flight pay off); a batch whose
-// rays all share one direction (orthographic shards) has light packets, for which every extra
-// wave repeats the upper-tree walk and the cluster tests.  ext12 = the ray
-// extents of the coherence pass (order-preserving uints: minima then maxima of d, o).
-__global__ void choose_split_kernel(const uint32_t* __restrict__ ext12, int n_packets, int launched,
-                                    int* __restrict__ split_dev, const uint32_t* __restrict__ lat_flag)
-{
-    const bool one_direction = ext12[0] == ext12[6] && ext12[1] == ext12[7] && ext12[2] == ext12[8];
-    int k = launched;
-    // (a scene with spheres smaller than the ray spacing has packets of very unequal weight: it
-    // keeps every launched wave -- see lat_split in launch_trace)
-    if (one_direction && !(lat_flag && *lat_flag != 0u)) {
-        // Measured on 1/8 ... 1/1 shards of the 1024^2 frame (2048 ... 16384 packets): best K =
-        // 4, 2, 2, 1.  The split kernels run 8 waves per SIMD: 8192 waves fill the chip once;
-        // from 6144 packets on a second wave per packet still pays (16384 waves).
-        k = 1;
-        while (k < launched && n_packets * k < 8192) k *= 2;
-        if (k < launched && n_packets >= 6144 && n_packets * k < 16384) k *= 2;
-    }
-    *split_dev = k;
-}
-
 int g_split = -1; // waves per packet; -1: automatic
 // waves per packet for big batches of scenes with sub-spacing spheres (measurement switch:
 // GRACE_LAT_SPLIT=0 keeps one wave per packet; 2, 4 (default), 8)
@@ -2016,7 +2021,27 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             g_hits.capacity = need;
         }
     }
-    uint32_t* ray_ext = nullptr;
+    // Per-hit and triangle traces cannot split a packet among waves (their outputs are ordered
+    // / reduced per ray inside one wave); with few rays they use narrower packets instead:
+    // 2-4x the waves, each with a tighter beam, on a chip that would otherwise sit idle.
+    int width = 64;
+    if (g_width > 0) width = g_width;
+    else if ((MODE == MODE_HITS && !hits_split) || MODE == MODE_TRI || MODE == MODE_COUNT_D4
+             || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4)
+        while (width > 16 && ceil_div(n_rays, size_t(width)) < 4096) width /= 2;
+    a.width = width;
+    const int n_packets = ceil_div(n_rays, size_t(width));
+    // Waves per packet: two resident sets of waves (2 x 8192) for small ray batches.
+    int split = 1;
+    if (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) {
+        if (g_split > 0) split = g_split;
+        else while (split < SUM_CLASSES && size_t(n_packets) * split < 16384) split *= 2;
+    }
+    if (hits_split) split = hit_split;
+    a.split = split;
+    a.split_dev = nullptr;
+    // (the working waves per packet are chosen on the device, by ray_keys_kernel)
+    const bool dev_split = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) && split > 1 && g_split <= 0;
     {
         constexpr bool need_b = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
         const bool fast_b = MODE == MODE_CUMULATIVE && !g_exact_integrals;
@@ -2093,8 +2118,10 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             GRACE_CHECK_LAUNCH();
             constexpr bool lat_mode = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
             ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(
-                a.rays, int(n_rays), ext, keys, a.C + 2 * n_clusters, lat_mode ? ext + 13 : nullptr);
+                a.rays, int(n_rays), ext, keys, a.C + 2 * n_clusters, lat_mode ? ext + 13 : nullptr,
+                n_packets, split, dev_split ? reinterpret_cast<int*>(ext + 12) : nullptr);
             if (lat_mode) a.lat_dev = reinterpret_cast<const int*>(ext + 13);
+            if (dev_split) a.split_dev = reinterpret_cast<const int*>(ext + 12);
             GRACE_CHECK_LAUNCH();
             // Only the key bits that decide which PACKET a ray joins need sorting: the order of
             // the rays inside a packet is irrelevant (log2(packets) + 2 bits, in whole 8-bit
@@ -2106,38 +2133,11 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             const int begin_bit = want_bits >= 30 ? 0 : 30 - want_bits;
             GRACE_TRY(sort_pairs_u32_nested(keys, nullptr, n_rays, 0, begin_bit, 30, perm, stream));
             a.perm = perm;
-            ray_ext = ext;
         }
     }
     a.n_rays = int(n_rays);
     a.n_nodes = int(n_nodes);
     a.status = g_status;
-    // Per-hit and triangle traces cannot split a packet among waves (their outputs are ordered
-    // / reduced per ray inside one wave); with few rays they use narrower packets instead:
-    // 2-4x the waves, each with a tighter beam, on a chip that would otherwise sit idle.
-    int width = 64;
-    if (g_width > 0) width = g_width;
-    else if ((MODE == MODE_HITS && !hits_split) || MODE == MODE_TRI || MODE == MODE_COUNT_D4
-             || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4)
-        while (width > 16 && ceil_div(n_rays, size_t(width)) < 4096) width /= 2;
-    a.width = width;
-    const int n_packets = ceil_div(n_rays, size_t(width));
-    // Waves per packet: two resident sets of waves (2 x 8192) for small ray batches.
-    int split = 1;
-    if (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) {
-        if (g_split > 0) split = g_split;
-        else while (split < SUM_CLASSES && size_t(n_packets) * split < 16384) split *= 2;
-    }
-    if (hits_split) split = hit_split;
-    a.split = split;
-    a.split_dev = nullptr;
-    if ((MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) && split > 1 && g_split <= 0 && ray_ext) {
-        int* split_dev = reinterpret_cast<int*>(ray_ext + 12);
-        choose_split_kernel<<<1, 1, 0, stream>>>(ray_ext, n_packets, split, split_dev,
-                                                 a.lat_dev ? ray_ext + 13 : nullptr);
-        GRACE_CHECK_LAUNCH();
-        a.split_dev = split_dev;
-    }
     a.n_prims = int(n_spheres);
     a.chunk_shift = hit_chunk_shift;
     a.n_chunks = hit_chunks;
