@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--particles", type=int, default=10_000_000)
     ap.add_argument("--side", type=int, default=1024)
+    ap.add_argument("--no-prepare-rays", action="store_true",
+                    help="recompute the ray coherence order (extents, keys, partial sort) in every "
+                         "trace call instead of once before the loop (grace_trace_prepare_rays)")
     ap.add_argument("--max-per-leaf", type=int, default=32)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -286,6 +289,17 @@ def main():
         torch.cuda.synchronize()
         unprepared_ms = 1e3 * (time.perf_counter() - t1) / 5
         gh.trace_prepare(spheres, tree)
+    # ... and without the prepared ray batch (every call then recomputes the ray coherence order:
+    # extents, keys, partial sort -- the reference's generators sort rays once, at generation).
+    unordered_ms = None
+    if not args.no_prepare_rays:
+        trace_once(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            trace_once()
+        torch.cuda.synchronize()
+        unordered_ms = 1e3 * (time.perf_counter() - t1) / 5
+        gh.trace_prepare_rays(my_rays)
 
     for _ in range(args.warmup):
         image = step()
@@ -408,6 +422,7 @@ def main():
                        "particles": n, "rays": n_rays, "frames": frames,
                        "max_per_leaf": args.max_per_leaf,
                        "scene_prepared": not args.no_prepare,
+                       "rays_prepared": not args.no_prepare_rays,
                        "sharding": "%d frame(s) of %d rays, contiguous ray shards over %d "
                                    "rank(s), BVH replicated, all_gather of 4 B/ray"
                                    % (frames, frame_rays, world)},
@@ -416,11 +431,13 @@ def main():
                           total_ms=round(sum(phases.values()), 4)),
             "image": {"mean": float(img.mean()), "max": float(img.max())},
             "unprepared_ms_per_call": None if unprepared_ms is None else round(unprepared_ms, 4),
+            "ray_order_per_call_ms_per_call": None if unordered_ms is None else round(unordered_ms, 4),
             "bit_exact_integrals": None if exact_ms is None else
                 {"ms_per_step": round(exact_ms, 4), "Mrays/s": round(n_rays / exact_ms / 1e3, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
             gh.trace_release()
+            gh.trace_release_rays()
             tree_host = (tree.nodes.cpu().numpy().view(np.float32).reshape(-1, 16),
                          tree.leaves.cpu().numpy(), int(tree.root_index.item()))
             out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), rays.cpu().numpy(), tree_host)

@@ -102,5 +102,7 @@ grace_status sort_pairs_u64_nested(uint64_t* d_keys, void* d_values, size_t n, i
 
 // Drops the prepared trace scene (grace_trace_prepare_*) if it was built over d_written.
 grace_status scene_invalidate_if_written(const void* d_written);
+// ... and a prepared ray batch (grace_trace_prepare_rays) when a ray generator writes to its array.
+grace_status rays_invalidate_if_written(const void* d_written);
 
 } // namespace grace_hip

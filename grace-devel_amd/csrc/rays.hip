@@ -276,6 +276,7 @@ grace_status grace_rays_orthogonal_z(int n_side, const float* h_mins4, const flo
                                      void* d_rays, float* h_area, grace_stream stream)
 {
     GRACE_REQUIRE(n_side > 0 && h_mins4 && h_maxs4 && d_rays, "orthogonal_rays_z: bad argument");
+    GRACE_TRY(rays_invalidate_if_written(d_rays));   // a prepared ray batch over this array is stale
     GRACE_REQUIRE(size_t(n_side) * n_side < (size_t(1) << 31), "orthogonal_rays_z: too many rays");
     // box_center / box_span, tests/helper/rays.cuh:11-29 (float sums, double halving).
     const float cx = float((h_mins4[0] + h_maxs4[0]) / 2.);
@@ -301,6 +302,7 @@ grace_status grace_rays_healpix(int nside, float ox, float oy, float oz, float l
 {
     GRACE_REQUIRE(nside >= 1 && nside <= 8192 && (nside & (nside - 1)) == 0 && d_rays,
                   "healpix: nside must be a power of two in [1, 8192]");
+    GRACE_TRY(rays_invalidate_if_written(d_rays));   // a prepared ray batch over this array is stale
     const size_t n = 12 * size_t(nside) * nside;
     healpix_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
         nside, ox, oy, oz, length, static_cast<float*>(d_rays));
@@ -314,6 +316,7 @@ grace_status grace_rays_pinhole(int res_x, int res_y, const float* h_camera, con
 {
     GRACE_REQUIRE(res_x > 0 && res_y > 0 && h_camera && h_look_at && h_view_up && d_rays,
                   "pinhole rays: bad argument");
+    GRACE_TRY(rays_invalidate_if_written(d_rays));   // a prepared ray batch over this array is stale
     // pinhole_camera_rays, gen_rays.cuh:727-789 (Real = float; normalize3 in fp64 on the host)
     const float* c = h_camera;
     float vd[3] = { h_look_at[0] - c[0], h_look_at[1] - c[1], h_look_at[2] - c[2] };
@@ -343,6 +346,7 @@ static grace_status isotropic_rays(size_t n_rays, float ox, float oy, float oz, 
                                    uint64_t seed, int octant, void* d_rays, grace_stream stream)
 {
     GRACE_REQUIRE(n_rays > 0 && d_rays, "isotropic rays: bad argument");
+    GRACE_TRY(rays_invalidate_if_written(d_rays));   // a prepared ray batch over this array is stale
     hipStream_t st = as_stream(stream);
     GRACE_TRY(Workspace::begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28), st));
     uint32_t* keys = Workspace::take<uint32_t>(n_rays);
@@ -372,6 +376,7 @@ grace_status grace_rays_one_to_many(size_t n_rays, float ox, float oy, float oz,
                                     void* d_rays, grace_stream stream)
 {
     GRACE_REQUIRE(n_rays > 0 && d_points && d_rays, "one_to_many_rays: bad argument");
+    GRACE_TRY(rays_invalidate_if_written(d_rays));   // a prepared ray batch over this array is stale
     GRACE_REQUIRE(elems_per_point >= 3 && elems_per_point <= 16,
                   "one_to_many_rays: elements per point must be 3..16");
     // gen_rays.cuh:126-131: an unknown sort type throws std::invalid_argument
@@ -406,6 +411,7 @@ grace_status grace_rays_plane_parallel_random(int width, int height, const float
 {
     GRACE_REQUIRE(width > 0 && height > 0 && h_base && h_w && h_h && d_rays,
                   "plane_parallel_random_rays: bad argument");
+    GRACE_TRY(rays_invalidate_if_written(d_rays));   // a prepared ray batch over this array is stale
     const size_t n = size_t(width) * height;
     GRACE_REQUIRE(n < (size_t(1) << 31), "plane_parallel_random_rays: too many rays");
     // gen_rays.cuh:628-642 (Real3 = float3)
@@ -428,6 +434,7 @@ grace_status grace_rays_orthographic_projection(int res_x, int res_y, const floa
 {
     GRACE_REQUIRE(res_x > 0 && res_y > 0 && h_camera && h_look_at && h_view_up && d_rays,
                   "orthographic_projection_rays: bad argument");
+    GRACE_TRY(rays_invalidate_if_written(d_rays));   // a prepared ray batch over this array is stale
     // gen_rays.cuh:667-725 (Real = float)
     const float aspect = float(res_x) / res_y;
     const float horizontal_extent = vertical_extent * aspect;

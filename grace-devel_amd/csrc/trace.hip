@@ -553,17 +553,15 @@ __device__ __forceinline__ uint32_t hilbert2d_15(uint32_t x, uint32_t y)
     return d;
 }
 
-__global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__ rays, int n,
-                                                       const uint32_t* __restrict__ ext12,
-                                                       uint32_t* __restrict__ keys,
-                                                       const float4* __restrict__ scene_min,
-                                                       uint32_t* __restrict__ lat_flag,
-                                                       int split_packets, int split_launched,
-                                                       int* __restrict__ split_dev)
+// Device-side choices of a trace launch, made by one thread from the batch's ray extents:
+// choose_lattice -- the LAT instantiation runs if all rays share one axis-aligned direction and the
+// scene holds spheres smaller than the diagonal of the batch's mean ray cell -- and choose_split
+// (class-split hit-count / cumulative launches): how many of the launched waves per packet work.
+__device__ void choose_variants(const uint32_t* __restrict__ ext12, int n, const float4* __restrict__ scene_min,
+                                uint32_t* __restrict__ lat_flag, int split_packets, int split_launched,
+                                int* __restrict__ split_dev)
 {
-    // choose_lattice: the LAT instantiation runs if all rays share one axis-aligned direction and
-    // the scene holds spheres smaller than the diagonal of the batch's mean ray cell.
-    if (lat_flag && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (lat_flag) {
         int n_dir = 0;
         bool one_dir = true;
         float e1 = 0.f, e2 = 0.f;   // the two largest origin extents
@@ -578,10 +576,28 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
         const float r2_min = scene_min->x;
         *lat_flag = (one_dir && n_dir == 1 && spacing2 > 0.f && r2_min < 2.0f * spacing2) ? 1u : 0u;
     }
-    // choose_split (class-split hit-count / cumulative launches): how many of the launched waves
-    // per packet work
-    if (split_dev && blockIdx.x == 0 && threadIdx.x == 0)
+    if (split_dev)
         *split_dev = choose_split(ext12, split_packets, split_launched, lat_flag ? *lat_flag != 0u : false);
+}
+
+// The same choices for a call whose ray order is cached (grace_trace_prepare_rays).
+__global__ void choose_variants_kernel(const uint32_t* __restrict__ ext12, int n, const float4* __restrict__ scene_min,
+                                       uint32_t* __restrict__ lat_flag, int split_packets, int split_launched,
+                                       int* __restrict__ split_dev)
+{
+    choose_variants(ext12, n, scene_min, lat_flag, split_packets, split_launched, split_dev);
+}
+
+__global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__ rays, int n,
+                                                       const uint32_t* __restrict__ ext12,
+                                                       uint32_t* __restrict__ keys,
+                                                       const float4* __restrict__ scene_min,
+                                                       uint32_t* __restrict__ lat_flag,
+                                                       int split_packets, int split_launched,
+                                                       int* __restrict__ split_dev)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        choose_variants(ext12, n, scene_min, lat_flag, split_packets, split_launched, split_dev);
     float lo[6], scale[6], span[6];
     int nvar = 0;
     // One scale for the three direction components and one for the three origin components (the
@@ -1961,6 +1977,79 @@ grace_status scene_prepare(bool tri, const void* prims, size_t n_prims, const in
     return GRACE_OK;
 }
 
+// Prepared ray batch (grace_trace_prepare_rays): the ray coherence order -- extents, keys, the
+// partial sort: ten small launches, ~0.08 ms, a seventh of a 1/8-image shard's call -- depends on
+// the rays alone.  The reference leaves ray ordering to the caller (its generators sort at
+// generation time, gen_rays.cuh:483,520,577,615); a caller that traces the SAME batch repeatedly
+// (a fixed camera over an evolving scene, a benchmark loop) computes it once here.  Keyed on
+// (pointer, count): the caller promises not to change the rays until grace_trace_release_rays();
+// this library's own ray generators drop the cache when they write to the array.
+struct RayOrder {
+    bool valid = false;
+    const float* rays = nullptr;
+    size_t n = 0;
+    uint32_t* perm = nullptr;   // n
+    uint32_t* ext = nullptr;    // 12 extents (order-preserving uints: minima then maxima of d, o)
+};
+RayOrder g_rays;
+
+grace_status rays_release()
+{
+    if (g_rays.perm || g_rays.ext) GRACE_TRY_HIP(hipDeviceSynchronize());
+    if (g_rays.perm) GRACE_TRY_HIP(hipFree(g_rays.perm));
+    if (g_rays.ext) GRACE_TRY_HIP(hipFree(g_rays.ext));
+    g_rays = RayOrder();
+    return GRACE_OK;
+}
+
+// extents -> keys -> partial sort (see launch_trace); keys: n words of scratch
+grace_status ray_order(const float* d_rays, size_t n_rays, uint32_t* ext, uint32_t* keys, uint32_t* perm,
+                       const float4* scene_min, uint32_t* lat_flag, int n_packets, int split, int* split_dev,
+                       hipStream_t stream)
+{
+    GRACE_TRY_HIP(hipMemsetAsync(ext, 0xFF, 24, stream));
+    GRACE_TRY_HIP(hipMemsetAsync(ext + 6, 0x00, 24, stream));
+    ray_extents_kernel<<<(stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256), 256, 0, stream>>>(
+        d_rays, int(n_rays), ext);
+    GRACE_CHECK_LAUNCH();
+    ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(d_rays, int(n_rays), ext, keys, scene_min,
+                                                                 lat_flag, n_packets, split, split_dev);
+    GRACE_CHECK_LAUNCH();
+    // Only the key bits that decide which PACKET a ray joins need sorting: the order of
+    // the rays inside a packet is irrelevant (log2(packets) + 2 bits, in whole 8-bit
+    // passes; keys are left-aligned in 30 bits).  The sort is stable, so ties keep the
+    // caller's order.
+    const size_t packets64 = ceil_div(n_rays, size_t(64));
+    int want_bits = 2;
+    while ((size_t(1) << (want_bits - 2)) < packets64 && want_bits < 30) ++want_bits;
+    want_bits = ((want_bits + 7) / 8) * 8;
+    const int begin_bit = want_bits >= 30 ? 0 : 30 - want_bits;
+    return sort_pairs_u32_nested(keys, nullptr, n_rays, 0, begin_bit, 30, perm, stream);
+}
+
+grace_status rays_prepare(const float* d_rays, size_t n_rays, hipStream_t stream)
+{
+    GRACE_REQUIRE(d_rays || n_rays == 0, "trace_prepare_rays: null pointer");
+    GRACE_REQUIRE(n_rays < (size_t(1) << 31), "trace_prepare_rays: bad ray count");
+    GRACE_TRY(rays_release());
+    if (n_rays <= 64) return GRACE_OK;          // one packet: nothing to order
+    RayOrder ro;
+    if (hipMalloc(reinterpret_cast<void**>(&ro.perm), n_rays * 4) != hipSuccess
+        || hipMalloc(reinterpret_cast<void**>(&ro.ext), 64) != hipSuccess) {
+        if (ro.perm) (void)hipFree(ro.perm);
+        return set_error(GRACE_OUT_OF_MEMORY, __FILE__, __LINE__, "trace_prepare_rays: out of device memory");
+    }
+    g_rays = ro;
+    grace_status st = Workspace::begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 0) + 1024, stream);
+    if (st == GRACE_OK) {
+        uint32_t* keys = Workspace::take<uint32_t>(n_rays);
+        st = ray_order(d_rays, n_rays, ro.ext, keys, ro.perm, nullptr, nullptr, 0, 0, nullptr, stream);
+    }
+    if (st != GRACE_OK) { rays_release(); return st; }
+    g_rays.valid = true; g_rays.rays = d_rays; g_rays.n = n_rays;
+    return GRACE_OK;
+}
+
 // trace_sph walks twice -- hit counts (for the offsets), then the per-hit pass -- and the split
 // per-hit pass of small batches needs hits per (ray, chunk), a third walk.  The hit-count call
 // made on behalf of trace_sph (grace_trace_hitcounts_keep_f4) records them into this buffer of
@@ -2108,31 +2197,28 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         a.treelet_axis = (MODE == MODE_STATS) ? 0 : (g_treelet < 0 ? auto_treelet_axis : g_treelet);
 #endif
         if (reorder) {
-            uint32_t* ext = Workspace::take<uint32_t>(16);   // 12 extents + the device-side split
+            // ext: 12 extents + [12] the device-side split + [13] the lattice flag (per call)
+            uint32_t* ext = Workspace::take<uint32_t>(16);
             uint32_t* keys = Workspace::take<uint32_t>(n_rays);
             uint32_t* perm = Workspace::take<uint32_t>(n_rays);
-            GRACE_TRY_HIP(hipMemsetAsync(ext, 0xFF, 24, stream));
-            GRACE_TRY_HIP(hipMemsetAsync(ext + 6, 0x00, 24, stream));
-            ray_extents_kernel<<<(stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256), 256, 0, stream>>>(a.rays, int(n_rays),
-                                                                              ext);
-            GRACE_CHECK_LAUNCH();
             constexpr bool lat_mode = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
-            ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(
-                a.rays, int(n_rays), ext, keys, a.C + 2 * n_clusters, lat_mode ? ext + 13 : nullptr,
-                n_packets, split, dev_split ? reinterpret_cast<int*>(ext + 12) : nullptr);
+            uint32_t* lat_flag = lat_mode ? ext + 13 : nullptr;
+            int* split_dev = dev_split ? reinterpret_cast<int*>(ext + 12) : nullptr;
+            if (g_rays.valid && g_rays.rays == a.rays && g_rays.n == n_rays) {
+                // prepared ray batch: only this call's device-side choices remain
+                if (lat_flag || split_dev) {
+                    choose_variants_kernel<<<1, 1, 0, stream>>>(g_rays.ext, int(n_rays), a.C + 2 * n_clusters, lat_flag,
+                                                                n_packets, split, split_dev);
+                    GRACE_CHECK_LAUNCH();
+                }
+                a.perm = g_rays.perm;
+            } else {
+                GRACE_TRY(ray_order(a.rays, n_rays, ext, keys, perm, a.C + 2 * n_clusters, lat_flag, n_packets,
+                                    split, split_dev, stream));
+                a.perm = perm;
+            }
             if (lat_mode) a.lat_dev = reinterpret_cast<const int*>(ext + 13);
             if (dev_split) a.split_dev = reinterpret_cast<const int*>(ext + 12);
-            GRACE_CHECK_LAUNCH();
-            // Only the key bits that decide which PACKET a ray joins need sorting: the order of
-            // the rays inside a packet is irrelevant (log2(packets) + 2 bits, in whole 8-bit
-            // passes; keys are left-aligned in 30 bits).  The sort is stable, so ties keep the
-            // caller's order.
-            int want_bits = 2;
-            while ((size_t(1) << (want_bits - 2)) < hit_packets && want_bits < 30) ++want_bits;
-            want_bits = ((want_bits + 7) / 8) * 8;
-            const int begin_bit = want_bits >= 30 ? 0 : 30 - want_bits;
-            GRACE_TRY(sort_pairs_u32_nested(keys, nullptr, n_rays, 0, begin_bit, 30, perm, stream));
-            a.perm = perm;
         }
     }
     a.n_rays = int(n_rays);
@@ -2311,6 +2397,12 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
 namespace grace_hip {
 // Called by this library's entry points that WRITE caller arrays (sort payloads, tree builds):
 // a prepared scene over that array is stale from here on.
+grace_status rays_invalidate_if_written(const void* d_written)
+{
+    if (g_rays.valid && d_written && d_written == static_cast<const void*>(g_rays.rays)) return rays_release();
+    return GRACE_OK;
+}
+
 grace_status scene_invalidate_if_written(const void* d_written)
 {
     if (g_scene.valid && d_written
@@ -2508,6 +2600,16 @@ grace_status grace_trace_prepare_tri(const float* d_tris, size_t n_tris, const i
                                      size_t n_nodes, const int* d_leaves, grace_stream stream)
 {
     return scene_prepare(true, d_tris, n_tris, d_nodes, n_nodes, d_leaves, as_stream(stream));
+}
+
+grace_status grace_trace_prepare_rays(const void* d_rays, size_t n_rays, grace_stream stream)
+{
+    return rays_prepare(static_cast<const float*>(d_rays), n_rays, as_stream(stream));
+}
+
+grace_status grace_trace_release_rays(void)
+{
+    return rays_release();
 }
 
 grace_status grace_trace_release(void)

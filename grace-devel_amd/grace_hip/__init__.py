@@ -309,6 +309,15 @@ def trace_prepare_tri(tris, tree):
                                         _ptr(tree.leaves), _stream()))
 
 
+def trace_prepare_rays(rays):
+    """Compute the coherence order of this ray batch once; later traces of the same tensor reuse it."""
+    _check(_lib.grace_trace_prepare_rays(_ptr(_rays(rays)), C.c_size_t(len(rays)), _stream()))
+
+
+def trace_release_rays():
+    _check(_lib.grace_trace_release_rays())
+
+
 def trace_release():
     _check(_lib.grace_trace_release())
 

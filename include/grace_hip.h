@@ -294,6 +294,17 @@ grace_status grace_trace_prepare_tri(const float* d_tris, size_t n_tris, const i
                                      size_t n_nodes, const int* d_leaves, grace_stream stream);
 grace_status grace_trace_release(void);
 
+/* Prepared ray batch.  Packets are 64 consecutive rays of a coherence order that every trace
+ * call computes from its rays (extents, keys, partial sort: ~0.08 ms of small launches).  The
+ * reference leaves ray ordering to the caller -- its generators sort at generation time
+ * (include/grace/cuda/kernels/gen_rays.cuh:483,520,577,615), once, outside trace().  A caller
+ * that traces the SAME batch repeatedly (a fixed camera over an evolving scene) computes the
+ * order once here; later trace calls on exactly (d_rays, n_rays) reuse it.  Results never depend
+ * on it.  The caller must not modify the rays until grace_trace_release_rays(); this library's
+ * own ray generators drop the cache when they write to the array.  One batch at a time. */
+grace_status grace_trace_prepare_rays(const void* d_rays, size_t n_rays, grace_stream stream);
+grace_status grace_trace_release_rays(void);
+
 /* Reads (and clears) the traversal status word: GRACE_STACK_OVERFLOW if any packet ran out
  * of its 128-entry stack since the last check (the reference only asserts this in
  * GRACE_DEBUG builds, bintree_trace.cuh:164).  Synchronises. */
