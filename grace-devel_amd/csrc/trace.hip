@@ -553,6 +553,51 @@ __device__ __forceinline__ uint32_t hilbert2d_15(uint32_t x, uint32_t y)
     return d;
 }
 
+// Is the batch a power-of-two pixel grid?  (Two varying co-ordinates, N1 x N2 = n points with N1,
+// N2 powers of two >= 8, every ray on a lattice point.)  Such a batch gets Z-order keys: the
+// tiles are the Hilbert curve's, but in the order that spreads a CU's workgroups evenly over its
+// XCD's block (5 % on a 1/8-image shard); every other batch gets the Hilbert
+// curve, whose runs never join distant patches.  flag: 0 on entry; any thread that finds the
+// batch unfit sets it.
+__global__ __launch_bounds__(256) void ray_lattice_kernel(const float* __restrict__ rays, int n,
+                                                          const uint32_t* __restrict__ ext12,
+                                                          uint32_t* __restrict__ flag)
+{
+    int dims[2] = { 0, 0 }, nvar = 0;
+    float lo[2] = { 0.f, 0.f }, span[2] = { 0.f, 0.f };
+    for (int k = 5; k >= 0; --k) {          // (the order ray_keys_kernel takes them in)
+        const float l = ord2f_u(ext12[k]), sp = ord2f_u(ext12[6 + k]) - l;
+        if (sp > 0.f && sp < INFINITY) {
+            if (nvar < 2) { dims[nvar] = k; lo[nvar] = l; span[nvar] = sp; }
+            ++nvar;
+        }
+    }
+    bool fit = nvar == 2 && n >= 64 && (n & (n - 1)) == 0;
+    float m1 = 0.f, m2 = 0.f;                // N1 - 1, N2 - 1
+    if (fit) {
+        int log_n = 0;
+        while ((1 << log_n) < n) ++log_n;
+        fit = false;
+        const float ratio = span[0] / span[1];
+        for (int a = 3; a <= log_n - 3; ++a) {
+            const float c1 = float((1 << a) - 1), c2 = float((1 << (log_n - a)) - 1);
+            if (fabsf(c1 / c2 - ratio) <= 1e-3f * ratio) { fit = true; m1 = c1; m2 = c2; break; }
+        }
+    }
+    if (!fit) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag, 1u);
+        return;
+    }
+    const float s1 = m1 / span[0], s2 = m2 / span[1];
+    bool off = false;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* r = rays + 7 * size_t(i);
+        const float u1 = (r[dims[0]] - lo[0]) * s1, u2 = (r[dims[1]] - lo[1]) * s2;
+        off = off || !(fabsf(u1 - rintf(u1)) <= 0.01f) || !(fabsf(u2 - rintf(u2)) <= 0.01f);
+    }
+    if (__builtin_amdgcn_ballot_w64(off) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 // Device-side choices of a trace launch, made by one thread from the batch's ray extents:
 // choose_lattice -- the LAT instantiation runs if all rays share one axis-aligned direction and the
 // scene holds spheres smaller than the diagonal of the batch's mean ray cell -- and choose_split
@@ -594,8 +639,10 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
                                                        const float4* __restrict__ scene_min,
                                                        uint32_t* __restrict__ lat_flag,
                                                        int split_packets, int split_launched,
-                                                       int* __restrict__ split_dev)
+                                                       int* __restrict__ split_dev,
+                                                       const uint32_t* __restrict__ not_grid)
 {
+    const bool z_order_2d = not_grid && *not_grid == 0u;   // a power-of-two pixel grid (ray_lattice_kernel)
     if (blockIdx.x == 0 && threadIdx.x == 0)
         choose_variants(ext12, n, scene_min, lat_flag, split_packets, split_launched, split_dev);
     float lo[6], scale[6], span[6];
@@ -654,7 +701,7 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
         // skew every 8x8 tile after it).
         for (int k = 0; k < 6; ++k) q[k] = uint32_t(fminf(qmax, (r[k] - lo[k]) * scale[k] * qmax + 0.5f));
 #ifndef GRACE_MORTON2D
-        if (nvar == 2) {
+        if (nvar == 2 && !z_order_2d) {
             // Two varying co-ordinates (orthographic and plane-parallel batches): the Hilbert curve
             // again.  A power-of-two pixel grid gives the same 8x8 tiles as the Z-order curve; any
             // other grid, or jittered origins, gives connected patches where Z-order runs straddle.
@@ -2008,12 +2055,15 @@ grace_status ray_order(const float* d_rays, size_t n_rays, uint32_t* ext, uint32
                        hipStream_t stream)
 {
     GRACE_TRY_HIP(hipMemsetAsync(ext, 0xFF, 24, stream));
-    GRACE_TRY_HIP(hipMemsetAsync(ext + 6, 0x00, 24, stream));
+    GRACE_TRY_HIP(hipMemsetAsync(ext + 6, 0x00, 40, stream));   // maxima, the per-call choices, the grid flag
     ray_extents_kernel<<<(stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256), 256, 0, stream>>>(
         d_rays, int(n_rays), ext);
     GRACE_CHECK_LAUNCH();
+    ray_lattice_kernel<<<(stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256), 256, 0, stream>>>(
+        d_rays, int(n_rays), ext, ext + 14);
+    GRACE_CHECK_LAUNCH();
     ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(d_rays, int(n_rays), ext, keys, scene_min,
-                                                                 lat_flag, n_packets, split, split_dev);
+                                                                 lat_flag, n_packets, split, split_dev, ext + 14);
     GRACE_CHECK_LAUNCH();
     // Only the key bits that decide which PACKET a ray joins need sorting: the order of
     // the rays inside a packet is irrelevant (log2(packets) + 2 bits, in whole 8-bit
