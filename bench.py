@@ -274,9 +274,17 @@ def main():
     def trace_once():
         gh.trace_cumulative_sph(my_rays, spheres, tree, my_out[: r1 - r0])
 
+    # A step = this rank's trace + the all-gather of the 4 B/ray results.  Two output buffers:
+    # the gather of step k (RCCL's own stream) overlaps the trace of step k + 1; every gather
+    # has finished when the timed region ends (GatherPipeline.drain + synchronize).
+    pipe = sharding.GatherPipeline(per, world, n_rays, dist, device)
+    step_no = [0]
+
     def step():
-        trace_once()
-        return sharding.gather_results(my_out, n_rays, world, dist)
+        k = step_no[0]; step_no[0] += 1
+        buf = pipe.buffer(k)
+        gh.trace_cumulative_sph(my_rays, spheres, tree, buf[: r1 - r0])
+        return pipe.gather(k)
 
     # The same step without the prepared scene (every call then recomputes the per-sphere
     # records, node spans and cluster boxes), for the record.
@@ -303,6 +311,7 @@ def main():
 
     for _ in range(args.warmup):
         image = step()
+    pipe.drain()
     # ---- the timed region: EXACTLY `steps` steps, nothing else in it, launches asynchronous --
     torch.cuda.synchronize()
     if world > 1:
@@ -311,6 +320,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         image = step()
+    pipe.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -424,7 +434,8 @@ def main():
                        "scene_prepared": not args.no_prepare,
                        "rays_prepared": not args.no_prepare_rays,
                        "sharding": "%d frame(s) of %d rays, contiguous ray shards over %d "
-                                   "rank(s), BVH replicated, all_gather of 4 B/ray"
+                                   "rank(s), BVH replicated, all_gather of 4 B/ray (two output "
+                                   "buffers: step k's gather overlaps step k+1's trace)"
                                    % (frames, frame_rays, world)},
             "roofline": roof,
             "build": dict(phases, n_leaves=tree.n_leaves,

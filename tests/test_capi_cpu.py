@@ -127,6 +127,20 @@ def _gloo_worker(rank, world, n_rays, port, q):
     mine[: hi - lo] = torch.arange(lo, hi, dtype=torch.float32) * 0.5 + 1.0
     full = sharding.gather_results(mine, n_rays, world, dist)
     ok = bool(torch.equal(full, torch.arange(n_rays, dtype=torch.float32) * 0.5 + 1.0))
+    # the double-buffered pipeline bench.py uses for N > 1: five steps, each step's results
+    # (a function of ray index and step) gathered while the next step fills the other buffer
+    pipe = sharding.GatherPipeline(per, world, n_rays, dist, "cpu")
+    outs = []
+    for k in range(5):
+        buf = pipe.buffer(k)
+        buf.fill_(-1.0)
+        buf[: hi - lo] = torch.arange(lo, hi, dtype=torch.float32) * 0.5 + 1.0 + k
+        outs.append((k, pipe.gather(k)))
+        if k >= 1:      # step k - 1's gather may be read once step k + 1 asks for its buffer again
+            pipe.buffer(k + 1)
+            ok = ok and bool(torch.equal(outs[k - 1][1], torch.arange(n_rays, dtype=torch.float32) * 0.5 + 1.0 + (k - 1)))
+    pipe.drain()
+    ok = ok and bool(torch.equal(outs[4][1], torch.arange(n_rays, dtype=torch.float32) * 0.5 + 1.0 + 4))
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, ok))
