@@ -2018,6 +2018,8 @@ grace_status scene_prepare(bool tri, const void* prims, size_t n_prims, const in
                     reinterpret_cast<const int4*>(d_leaves), sc.A, sc.B1, sc.B50, sc.T64,
                     sc.node_prims, sc.C, stream);
     if (st != GRACE_OK) { scene_release(); return st; }
+    // (a one-time call: wait for the records, so that traces on ANY stream may use them)
+    GRACE_TRY_HIP(hipStreamSynchronize(stream));
     g_scene.valid = true; g_scene.tri = tri;
     g_scene.prims = prims; g_scene.nodes = d_nodes; g_scene.leaves = d_leaves;
     g_scene.n_prims = n_prims; g_scene.n_nodes = n_nodes;
@@ -2096,6 +2098,11 @@ grace_status rays_prepare(const float* d_rays, size_t n_rays, hipStream_t stream
         st = ray_order(d_rays, n_rays, ro.ext, keys, ro.perm, nullptr, nullptr, 0, 0, nullptr, stream);
     }
     if (st != GRACE_OK) { rays_release(); return st; }
+    // (a one-time call: wait for the order, so that traces on ANY stream may use it)
+    if (hipStreamSynchronize(stream) != hipSuccess) {
+        rays_release();
+        return set_error(GRACE_HIP_ERROR, __FILE__, __LINE__, "trace_prepare_rays: stream synchronisation failed");
+    }
     g_rays.valid = true; g_rays.rays = d_rays; g_rays.n = n_rays;
     return GRACE_OK;
 }
