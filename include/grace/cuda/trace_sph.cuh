@@ -222,4 +222,26 @@ GRACE_HOST void trace_with_sentinels_sph(
     detail::check_trace_status();
 }
 
+// ---- extensions (not in the reference) ------------------------------------------------------
+// Prepared scene and prepared ray batch: what every trace call otherwise recomputes from its
+// arguments (the scene's pre-pass records; the ray coherence order) is computed once for inputs
+// that are traced repeatedly.  Results never depend on it.  See grace_hip.h.
+GRACE_HOST inline void prepare_trace_sph(const thrust::device_vector<float4>& d_spheres, const Tree& d_tree)
+{
+    const detail::TreeArgs t = detail::tree_args(d_tree);
+    GRACE_STATUS_CHECK(grace_trace_prepare_f4(reinterpret_cast<const float*>(detail::raw(d_spheres)),
+                                              d_spheres.size(), t.nodes, t.n_nodes, t.leaves, NULL));
+}
+
+GRACE_HOST inline void prepare_trace_rays(const thrust::device_vector<Ray>& d_rays)
+{
+    GRACE_STATUS_CHECK(grace_trace_prepare_rays(detail::raw(d_rays), d_rays.size(), NULL));
+}
+
+GRACE_HOST inline void release_prepared_trace()
+{
+    GRACE_STATUS_CHECK(grace_trace_release());
+    GRACE_STATUS_CHECK(grace_trace_release_rays());
+}
+
 } // namespace grace
