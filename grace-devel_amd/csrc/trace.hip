@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void cluster_boxes_kernel(const float4* __rest
 {
     const size_t n_clusters = (n + 63) / 64;
     const int lane = threadIdx.x & 63;
+    float wave_r2_min = INFINITY;   // over the clusters this wave handles (lane 0)
     for (size_t c = blockIdx.x * size_t(blockDim.x / 64) + (threadIdx.x >> 6); c < n_clusters;
          c += size_t(gridDim.x) * (blockDim.x / 64)) {
         const size_t i = c * 64 + lane;
@@ -360,15 +361,24 @@ __global__ __launch_bounds__(256) void cluster_boxes_kernel(const float4* __rest
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) r2_min = fminf(r2_min, __shfl_xor(r2_min, off));
         if (lane == 0) {
-            // the scene's smallest r^2 (positive floats order like their bit patterns); one
-            // float4 past the last cluster record, pre-set to a huge value by scene_fill
-            atomicMin(reinterpret_cast<unsigned int*>(C + 2 * n_clusters), __float_as_uint(r2_min));
+            wave_r2_min = fminf(wave_r2_min, r2_min);
             // .w of the low corner: the smallest r^2 of the members (the origin-lattice cull of
             // axis-aligned packets looks only at clusters that hold spheres smaller than the
             // packet's ray spacing)
             C[2 * c] = make_float4(lo[0], lo[1], lo[2], r2_min);
             C[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
         }
+    }
+    // the scene's smallest r^2 (positive floats order like their bit patterns): one float4 past
+    // the last cluster record, pre-set to a huge value by scene_fill; one atomic per workgroup (one per
+    // cluster serialised 156 k atomics on one address at 10^7 primitives: +1.8 ms per unprepared call)
+    __shared__ float s_r2_min[4];
+    if (lane == 0) s_r2_min[(threadIdx.x >> 6) & 3] = wave_r2_min;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = s_r2_min[0];
+        for (unsigned w = 1; w < blockDim.x / 64 && w < 4; ++w) m = fminf(m, s_r2_min[w]);
+        if (m < INFINITY) atomicMin(reinterpret_cast<unsigned int*>(C + 2 * n_clusters), __float_as_uint(m));
     }
 }
 
@@ -2243,9 +2253,13 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         // Subtrees of up to this many primitives are swept -- cluster tests, then culling rounds
         // over the surviving clusters -- rather than descended.
         // Axis-aligned packets test a cluster's box against their origin rectangle (sharp: large
-        // subtrees pay, 16384 measured best on full frames and shards alike); other packets test
-        // the box's circumscribed sphere (blunt: 512, as without cluster tests).
-        const int auto_treelet = 512, auto_treelet_axis = 16384;
+        // subtrees pay, 16384 measured best on full frames and shards alike); pencil packets test it
+        // against the bundle's side planes, general packets its circumscribed sphere.
+        // (re-measured after the pencil cluster test became a box-against-side-planes test: sphere
+        // scenes now prefer 8192 there too -- config 2 column densities 1.74 -> 1.46 ms, hit counts
+        // 1.54 -> 1.19, config 3 0.94 -> 0.87 --; triangles, culled through bounding spheres, keep 512:
+        // 5.3 / 4.6 / 2.8 ms for the three cameras against 6.9 / 5.8 / 3.0 at 8192)
+        const int auto_treelet = (MODE == MODE_TRI) ? 512 : 8192, auto_treelet_axis = 16384;
 #ifdef GRACE_PACKET_STATS
         a.treelet = g_treelet < 0 ? auto_treelet : g_treelet;
         a.treelet_axis = g_treelet < 0 ? auto_treelet_axis : g_treelet;
