@@ -293,6 +293,9 @@ def trace_status():
     _check(_lib.grace_trace_status(_stream()))
 
 
+_prepared = {}   # tensors behind the prepared scene / ray batch (kept alive: see trace_prepare)
+
+
 def trace_prepare(spheres, tree):
     """Computes the scene-constant trace data (per-sphere records, node spans, cluster boxes)
     once; later trace calls over the same spheres / tree reuse it until trace_release().  The
@@ -301,25 +304,32 @@ def trace_prepare(spheres, tree):
     _check(_lib.grace_trace_prepare_f4(_ptr(_spheres(spheres)), C.c_size_t(len(spheres)),
                                        _ptr(tree.nodes), C.c_size_t(tree.n_nodes),
                                        _ptr(tree.leaves), _stream()))
+    # The cache is keyed on device pointers: keep the tensors alive while it is, so that the
+    # allocator cannot hand their addresses to other data.
+    _prepared["scene"] = (spheres, tree.nodes, tree.leaves)
 
 
 def trace_prepare_tri(tris, tree):
     _check(_lib.grace_trace_prepare_tri(_ptr(_tris(tris)), C.c_size_t(len(tris)),
                                         _ptr(tree.nodes), C.c_size_t(tree.n_nodes),
                                         _ptr(tree.leaves), _stream()))
+    _prepared["scene"] = (tris, tree.nodes, tree.leaves)
 
 
 def trace_prepare_rays(rays):
     """Compute the coherence order of this ray batch once; later traces of the same tensor reuse it."""
     _check(_lib.grace_trace_prepare_rays(_ptr(_rays(rays)), C.c_size_t(len(rays)), _stream()))
+    _prepared["rays"] = rays       # (see trace_prepare)
 
 
 def trace_release_rays():
     _check(_lib.grace_trace_release_rays())
+    _prepared.pop("rays", None)
 
 
 def trace_release():
     _check(_lib.grace_trace_release())
+    _prepared.pop("scene", None)
 
 
 def _trace_hitcounts_keep(rays, spheres, tree, hit_counts):
