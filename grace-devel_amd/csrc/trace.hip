@@ -271,13 +271,74 @@ __device__ __forceinline__ float hit_integral_fast(const float b2, const float i
     return __builtin_fmaf(t, y.y, y.x);
 }
 
+// One wave, one cluster: the box of the 64 records a(i), i = 64 c + lane (lanes with i >= n hold
+// nothing); lane 0 writes the cluster record and returns the cluster's smallest r^2 in every lane.
+__device__ __forceinline__ float cluster_box_of_wave(const float4 s, const bool have, const size_t c,
+                                                     float4* __restrict__ C)
+{
+    const int lane = threadIdx.x & 63;
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    float r2_min = INFINITY;
+    if (have) {
+        r2_min = s.w;
+        const float r = sqrtf(s.w) * 1.00001f;   // sqrt(fl(h h)) can round below h
+        const float ctr[3] = { s.x, s.y, s.z };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float slack = (fabsf(ctr[k]) + r) * 4.76837158203125e-07f; // 2^-21
+            lo[k] = (ctr[k] - r) - slack;
+            hi[k] = (ctr[k] + r) + slack;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) r2_min = fminf(r2_min, __shfl_xor(r2_min, off));
+    if (lane == 0) {
+        // .w of the low corner: the smallest r^2 of the members (the origin-lattice cull of
+        // axis-aligned packets looks only at clusters that hold spheres smaller than the
+        // packet's ray spacing)
+        C[2 * c] = make_float4(lo[0], lo[1], lo[2], r2_min);
+        C[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+    return r2_min;
+}
+
+// The scene's smallest r^2 (positive floats order like their bit patterns): one float4 past the
+// last cluster record, pre-set to a huge value by scene_fill; one atomic per workgroup (one per
+// cluster serialised 156 k atomics on one address at 10^7 primitives: +1.8 ms per unprepared call).
+// Every thread of the workgroup must call it.
+__device__ __forceinline__ void publish_r2_min(const float wave_r2_min, float4* __restrict__ C_tail)
+{
+    __shared__ float s_r2_min[4];
+    if ((threadIdx.x & 63) == 0) s_r2_min[(threadIdx.x >> 6) & 3] = wave_r2_min;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = s_r2_min[0];
+        for (unsigned w = 1; w < blockDim.x / 64 && w < 4; ++w) m = fminf(m, s_r2_min[w]);
+        if (m < INFINITY) atomicMin(reinterpret_cast<unsigned int*>(C_tail), __float_as_uint(m));
+    }
+}
+
+// C != null: the cluster boxes in the same pass (a wave's 64 consecutive records ARE a cluster:
+// the loop stride is a multiple of the workgroup size) -- one launch and one read of A fewer.
 __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __restrict__ spheres,
                                                             size_t n, float4* __restrict__ A,
                                                             float2* __restrict__ B,
-                                                            const float b_scale)
+                                                            const float b_scale,
+                                                            float4* __restrict__ C = nullptr)
 {
-    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n + 4;
+    float wave_r2_min = INFINITY;
+    // (whole waves enter every iteration: the bound is rounded up to the wave's first record)
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; (i & ~size_t(63)) < n + 4;
          i += size_t(gridDim.x) * blockDim.x) {
+
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         float2 b = make_float2(0.f, 0.f);
         if (i < n) {
@@ -291,9 +352,14 @@ __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __rest
                 if (b_scale != 1.0f) b.y = fminf(b.y, 3.4028234664e38f);
             }
         }
-        A[i] = a;
-        if (B) B[i] = b;
+        if (i < n + 4) {
+            A[i] = a;
+            if (B) B[i] = b;
+        }
+        // (wave-uniform condition: every lane of the wave takes part in the shuffles)
+        if (C && (i & ~size_t(63)) < n) wave_r2_min = fminf(wave_r2_min, cluster_box_of_wave(a, i < n, i >> 6, C));
     }
+    if (C) publish_r2_min(wave_r2_min, C + 2 * ((n + 63) / 64));
 }
 
 // double4 spheres: the float record {x, y, z, r^2} that drives the walk's culls must CONTAIN the
@@ -332,54 +398,15 @@ __global__ __launch_bounds__(256) void cluster_boxes_kernel(const float4* __rest
 {
     const size_t n_clusters = (n + 63) / 64;
     const int lane = threadIdx.x & 63;
-    float wave_r2_min = INFINITY;   // over the clusters this wave handles (lane 0)
+    float wave_r2_min = INFINITY;   // over the clusters this wave handles
     for (size_t c = blockIdx.x * size_t(blockDim.x / 64) + (threadIdx.x >> 6); c < n_clusters;
          c += size_t(gridDim.x) * (blockDim.x / 64)) {
         const size_t i = c * 64 + lane;
-        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-        float r2_min = INFINITY;
-        if (i < n) {
-            const float4 s = A[i];
-            r2_min = s.w;
-            const float r = sqrtf(s.w) * 1.00001f;   // sqrt(fl(h h)) can round below h
-            const float ctr[3] = { s.x, s.y, s.z };
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float slack = (fabsf(ctr[k]) + r) * 4.76837158203125e-07f; // 2^-21
-                lo[k] = (ctr[k] - r) - slack;
-                hi[k] = (ctr[k] + r) + slack;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
-                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) r2_min = fminf(r2_min, __shfl_xor(r2_min, off));
-        if (lane == 0) {
-            wave_r2_min = fminf(wave_r2_min, r2_min);
-            // .w of the low corner: the smallest r^2 of the members (the origin-lattice cull of
-            // axis-aligned packets looks only at clusters that hold spheres smaller than the
-            // packet's ray spacing)
-            C[2 * c] = make_float4(lo[0], lo[1], lo[2], r2_min);
-            C[2 * c + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
-        }
+        const bool have = i < n;
+        const float4 s = have ? A[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        wave_r2_min = fminf(wave_r2_min, cluster_box_of_wave(s, have, c, C));
     }
-    // the scene's smallest r^2 (positive floats order like their bit patterns): one float4 past
-    // the last cluster record, pre-set to a huge value by scene_fill; one atomic per workgroup (one per
-    // cluster serialised 156 k atomics on one address at 10^7 primitives: +1.8 ms per unprepared call)
-    __shared__ float s_r2_min[4];
-    if (lane == 0) s_r2_min[(threadIdx.x >> 6) & 3] = wave_r2_min;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float m = s_r2_min[0];
-        for (unsigned w = 1; w < blockDim.x / 64 && w < 4; ++w) m = fminf(m, s_r2_min[w]);
-        if (m < INFINITY) atomicMin(reinterpret_cast<unsigned int*>(C + 2 * n_clusters), __float_as_uint(m));
-    }
+    publish_r2_min(wave_r2_min, C + 2 * n_clusters);
 }
 
 // ---- triangle primitives (tests/profile_trace_triangle) -----------------------------------
@@ -456,9 +483,13 @@ __device__ __forceinline__ bool tri_intersect(const double ddx, const double ddy
 // their primitives, [leaves[first].x, leaves[last].x + leaves[last].y).
 __global__ __launch_bounds__(256) void node_prims_kernel(const int4* __restrict__ nodes4,
                                                          const int4* __restrict__ leaves, int n_nodes,
-                                                         int2* __restrict__ out)
+                                                         int2* __restrict__ out,
+                                                         uint32_t* __restrict__ r2_min_slot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (the slot the cluster-box pass reduces the scene's smallest r^2 into starts out huge: this
+    // launch precedes that pass on the stream)
+    if (i == 0 && r2_min_slot) *r2_min_slot = 0x7f7f7f7fu;
     if (i >= n_nodes) return;
     const int4 n0 = nodes4[4 * size_t(i)];
     const int4 lf = leaves[n0.z], ll = leaves[n0.w];
@@ -482,6 +513,11 @@ __device__ __forceinline__ uint32_t f2ord_u(float f)
 __device__ __forceinline__ float ord2f_u(uint32_t u)
 {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ void ray_ext_init_kernel(uint32_t* __restrict__ ext16)
+{
+    if (threadIdx.x < 16) ext16[threadIdx.x] = threadIdx.x < 6 ? 0xFFFFFFFFu : 0u;
 }
 
 __global__ __launch_bounds__(256) void ray_extents_kernel(const float* __restrict__ rays, int n,
@@ -1976,7 +2012,8 @@ grace_status scene_fill(int kind, const void* prims, size_t n_prims, const float
                         double* T64, int2* node_prims, float4* C, hipStream_t stream)
 {
     node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
-        reinterpret_cast<const int4*>(nodes), leaves, int(n_nodes), node_prims);
+        reinterpret_cast<const int4*>(nodes), leaves, int(n_nodes), node_prims,
+        reinterpret_cast<uint32_t*>(C + 2 * ((n_prims + 63) / 64)));
     GRACE_CHECK_LAUNCH();
     if (kind == 1) {
         tri_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
@@ -1989,7 +2026,7 @@ grace_status scene_fill(int kind, const void* prims, size_t n_prims, const float
     } else {
         trace_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
             static_cast<const float4*>(prims), n_prims, A, B1 ? B1 : B50,
-            B1 ? 1.0f : float(N_TABLE - 1));
+            B1 ? 1.0f : float(N_TABLE - 1), C);      // (+ the cluster boxes: fused)
         GRACE_CHECK_LAUNCH();
         if (B1 && B50) {
             trace_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
@@ -1997,9 +2034,10 @@ grace_status scene_fill(int kind, const void* prims, size_t n_prims, const float
             GRACE_CHECK_LAUNCH();
         }
     }
-    GRACE_TRY_HIP(hipMemsetAsync(C + 2 * ((n_prims + 63) / 64), 0x7f, sizeof(float4), stream));
-    cluster_boxes_kernel<<<stream_grid((n_prims + 63) / 64, 4), 256, 0, stream>>>(A, n_prims, C);
-    GRACE_CHECK_LAUNCH();
+    if (kind != 0) {
+        cluster_boxes_kernel<<<stream_grid((n_prims + 63) / 64, 4), 256, 0, stream>>>(A, n_prims, C);
+        GRACE_CHECK_LAUNCH();
+    }
     return GRACE_OK;
 }
 
@@ -2066,8 +2104,10 @@ grace_status ray_order(const float* d_rays, size_t n_rays, uint32_t* ext, uint32
                        const float4* scene_min, uint32_t* lat_flag, int n_packets, int split, int* split_dev,
                        hipStream_t stream)
 {
-    GRACE_TRY_HIP(hipMemsetAsync(ext, 0xFF, 24, stream));
-    GRACE_TRY_HIP(hipMemsetAsync(ext + 6, 0x00, 40, stream));   // maxima, the per-call choices, the grid flag
+    // minima at the top of the order, maxima / per-call choices / grid flag at zero: one tiny launch
+    // (two hipMemsetAsync of 24 and 40 bytes became four fill kernels)
+    ray_ext_init_kernel<<<1, 64, 0, stream>>>(ext);
+    GRACE_CHECK_LAUNCH();
     ray_extents_kernel<<<(stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256), 256, 0, stream>>>(
         d_rays, int(n_rays), ext);
     GRACE_CHECK_LAUNCH();
