@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256) void ray_extents_kernel(const float* __restric
                                                           uint32_t* __restrict__ ext12)
 {
     float lo[6], hi[6];
+    float len_hi = -INFINITY;   // the longest ray (slot 15: choose_lattice's scale for one-origin batches)
 #pragma unroll
     for (int k = 0; k < 6; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -534,7 +535,11 @@ __global__ __launch_bounds__(256) void ray_extents_kernel(const float* __restric
             lo[k] = fminf(lo[k], v);
             hi[k] = fmaxf(hi[k], v);
         }
+        len_hi = fmaxf(len_hi, r[6]);
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) len_hi = fmaxf(len_hi, __shfl_xor(len_hi, off));
+    if ((threadIdx.x & 63) == 0 && len_hi > -INFINITY) atomicMax(&ext12[15], f2ord_u(len_hi));
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
 #pragma unroll
@@ -665,7 +670,16 @@ __device__ void choose_variants(const uint32_t* __restrict__ ext12, int n, const
         }
         const float spacing2 = e1 * e2 / float(n);
         const float r2_min = scene_min->x;
-        *lat_flag = (one_dir && n_dir == 1 && spacing2 > 0.f && r2_min < 2.0f * spacing2) ? 1u : 0u;
+        bool lat = one_dir && n_dir == 1 && spacing2 > 0.f && r2_min < 2.0f * spacing2;
+        // One origin (point sources, cameras): the rays' spacing at the far end of the longest ray,
+        // 4 pi L^2 / n for a full sphere (an upper bound for partial ones).  There is no lattice to
+        // cull against, but such scenes have the same very unequal packets: the flag sends the batch
+        // to four waves per packet (launch_trace) all the same.
+        if (!lat && e1 == 0.f && ext12[15] != 0u) {
+            const float len = ord2f_u(ext12[15]);
+            if (len > 0.f && len < INFINITY) lat = r2_min < 2.0f * (12.566371f * len * len / float(n));
+        }
+        *lat_flag = lat ? 1u : 0u;
     }
     if (split_dev)
         *split_dev = choose_split(ext12, split_packets, split_launched, lat_flag ? *lat_flag != 0u : false);

@@ -323,6 +323,30 @@ def test_clustered_scene_full_frame_splits_packets_and_stays_bit_identical(gh, o
     assert np.array_equal(out[-1][0][sub].cpu().numpy(), oracle.brute_hitcounts(rh, sh))
     c32, _ = oracle.brute_cumulative(rh, sh)
     assert np.array_equal(out[-1][1][sub].cpu().numpy().view(np.uint32), c32.view(np.uint32))
+    # the same for a big one-origin batch (HEALPix Nside 512: 49152 packets): no lattice to cull
+    # against, but the flag (ray spacing at the far end of the longest ray) splits its packets too
+    prays = gh.healpix_rays(512, (0.45, 0.5, 0.55), 1.5, device=cuda)
+    P = len(prays)
+    pout = {}
+    for K in (-1, 1):
+        gh.set_packet_split(K)
+        try:
+            hc = torch.empty(P, dtype=torch.int32, device=cuda); cu = torch.empty(P, dtype=torch.float32, device=cuda)
+            gh.trace_hitcounts_sph(prays, s, tree, hc, check=True)
+            assert gh.last_lattice() == 1
+            gh.set_exact_integrals(True)
+            gh.trace_cumulative_sph(prays, s, tree, cu, check=True)
+            gh.set_exact_integrals(False)
+            pout[K] = (hc, cu)
+        finally:
+            gh.set_packet_split(-1); gh.set_exact_integrals(False)
+    for a, b in zip(pout[-1], pout[1]):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    psub = torch.arange(0, P, P // 128, device=cuda)[:128]
+    ph = prays[psub].cpu().numpy()
+    assert np.array_equal(pout[-1][0][psub].cpu().numpy(), oracle.brute_hitcounts(ph, sh))
+    pc32, _ = oracle.brute_cumulative(ph, sh)
+    assert np.array_equal(pout[-1][1][psub].cpu().numpy().view(np.uint32), pc32.view(np.uint32))
 
 
 # ---- remaining instantiations -----------------------------------------------------------------
