@@ -2239,6 +2239,11 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     else if ((MODE == MODE_HITS && !hits_split) || MODE == MODE_TRI || MODE == MODE_COUNT_D4
              || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4)
         while (width > 16 && ceil_div(n_rays, size_t(width)) < 4096) width /= 2;
+    // Hit counts and column densities split packets eight ways at most; a batch too small to fill
+    // the chip even then (< 512 packets) also gets narrower packets (10^7 particles, 12288 HEALPix
+    // rays: 3.5 -> 2.0 ms at 16 rays per packet; from 49152 rays on it loses: config 3 0.87 -> 0.95 ms).
+    else if ((MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) && g_split <= 0)
+        while (width > 16 && ceil_div(n_rays, size_t(width)) * SUM_CLASSES < 4096) width /= 2;
     a.width = width;
     const int n_packets = ceil_div(n_rays, size_t(width));
     // Waves per packet: two resident sets of waves (2 x 8192) for small ray batches.
