@@ -19,7 +19,7 @@
 //   * the packet's stack lives in TWO VGPRs indexed by lane (pop = v_readlane, push =
 //     lane-select, with a scalar stack pointer): 128 entries, no LDS traffic;
 //   * node records are wave-uniform: child indices / primitive spans are consumed as scalars,
-//     the per-ray slab test keeps the reference's arithmetic (~320 node tests per packet);
+//     the per-ray slab test keeps the reference's arithmetic (~100 node tests per packet);
 //   * no FMA contraction (-ffp-contract=off), IEEE 1/x and sqrt in everything that decides a
 //     hit or feeds a bit-exact output: the reference's CPU/GPU equality test is built with
 //     -fmad=false (tests/tree_traversal/Makefile:5-8).  Explicit FMAs appear only where they
@@ -27,10 +27,20 @@
 //   * a streaming pre-pass hoists per-sphere work out of the (ray x sphere) loop:
 //     A[i] = {x, y, z, h*h}, B[i] = {1/h or 50/h, (1/h)^2};
 //   * ray coherence order: 64 consecutive rays of a space-filling order of the ray
-//     co-ordinates that vary (15-bit round-to-nearest keys; octahedral 2-D order for
-//     partial-sphere bundles from one origin) form a packet; results do not depend on it;
-//   * treelet sweep: a node whose subtree holds <= T primitives (contiguous indices; T = 512)
-//     is not descended: its primitives go through culling rounds of 64;
+//     co-ordinates that vary form a packet (15-bit round-to-nearest keys; a Hilbert curve for
+//     two varying co-ordinates and, over the octahedral map of the direction, for batches from
+//     one origin -- its runs never join distant patches; Z-order for power-of-two pixel grids,
+//     whose tiles are the same and whose tile order suits the dispatcher better, and for
+//     general batches); results do not depend on it; a batch traced repeatedly can have its
+//     order prepared once (grace_trace_prepare_rays);
+//   * treelet sweep with a cluster level: a node whose subtree holds <= T primitives (contiguous
+//     indices; T = 16384 for axis-aligned packets, 8192 otherwise, 512 for triangles) is not
+//     descended: one box per 64 consecutive primitives (a pre-pass) is tested first, lane j
+//     for cluster j, and only the surviving clusters go through culling rounds of 64;
+//   * scenes with spheres smaller than the ray spacing (dense cores of clustered SPH data) run
+//     a separate instantiation (LAT), selected by a device flag: an exact cull against the
+//     packet's origin lattice, and four waves per packet for big batches (their packets are
+//     very unequal);
 //   * beam culling per round, lane j deciding for candidate j whether ANY ray of the packet
 //     can hit it: exact lower bound of b^2 for axis-aligned packets (rounding is monotone),
 //     cone + four side planes for packets from one origin, interval arithmetic otherwise;
@@ -56,8 +66,9 @@
 //     work for any beam -- with NO change of the result: each wave reduces its classes, a
 //     tiny kernel finishes the tree.  K is the smallest power of two that puts >= 16384 waves
 //     in flight; for batches of one direction (light packets) a device-side choice lowers it
-//     to what reaches 4096 waves (choose_split).  A wave keeps its class accumulators in LDS (2 KiB) and switches at granule
-//     boundaries, once per culling round at most.  Hit counts split the same way (integers);
+//     (choose_split).  A wave keeps its class accumulators in LDS (2 KiB) and switches at
+//     granule boundaries, once per culling round at most.  Hit counts split the same way
+//     (integers);
 //   * per-hit outputs (ordered per ray): large batches stage hits per lane in LDS and drain
 //     them eight entries per ray; small batches split a packet over K waves by contiguous
 //     chunk ranges with per-(ray, chunk) output offsets from a counting walk (hits_plan_kernel);
