@@ -596,6 +596,26 @@ inline void trace_cumulative_sph(const device_vector<Ray>& d_rays,
     detail::check(grace_trace_status_d4(nullptr));
 }
 
+// Extensions (not in the reference; see grace_hip.h): what every trace call otherwise recomputes
+// from its arguments -- the scene's pre-pass records, the ray coherence order -- computed once for
+// inputs that are traced repeatedly.  Results never depend on it.
+inline void prepare_trace_sph(const device_vector<float4>& d_spheres, const Tree& d_tree)
+{
+    detail::check(grace_trace_prepare_f4(&d_spheres.data()->x, d_spheres.size(), &d_tree.nodes.data()->x,
+                                         d_tree.leaves.size() - 1, &d_tree.leaves.data()->x, nullptr));
+}
+
+inline void prepare_trace_rays(const device_vector<Ray>& d_rays)
+{
+    detail::check(grace_trace_prepare_rays(d_rays.data(), d_rays.size(), nullptr));
+}
+
+inline void release_prepared_trace()
+{
+    detail::check(grace_trace_release());
+    detail::check(grace_trace_release_rays());
+}
+
 // util/extrema.cuh min_vec4 / max_vec4 as used by tests/project_gadget/project_gadget.cu:66-68
 inline void min_max_vec4(const device_vector<float4>& d_v, float4* mins, float4* maxs)
 {
