@@ -32,6 +32,8 @@
 // small: deltas 8 B, flags/counts 12 B, sphere 16 B per primitive, 64 B per node.
 #include "common.hpp"
 
+#include <type_traits>
+
 using namespace grace_hip;
 
 namespace {
@@ -238,7 +240,11 @@ __device__ __forceinline__ void triangle_box(const float* __restrict__ t, float*
     }
 }
 
-enum { PRIM_SPHERE = 0, PRIM_TRIANGLE = 1, PRIM_SPHERE_D4 = 2 };
+// PRIM_BOX: the caller's own AABB functor already evaluated per primitive (the generic
+// build_ALBVH(..., AABBFunc) of grace/cuda/kernels/albvh.cuh: the functor runs in a header kernel
+// of the caller's translation unit, the tree builder here): 6 floats {bot xyz, top xyz}.
+enum { PRIM_SPHERE = GRACE_PRIM_SPHERE_F4, PRIM_TRIANGLE = GRACE_PRIM_TRIANGLE,
+       PRIM_SPHERE_D4 = GRACE_PRIM_SPHERE_D4, PRIM_BOX = GRACE_PRIM_BOX };
 
 // Leaf AABBs (albvh.cuh:402-424): eight lanes per leaf stride over its primitives, so a
 // wave reads eight runs of consecutive primitives (128 B each for spheres), then an
@@ -257,7 +263,11 @@ __global__ __launch_bounds__(256) void leaf_boxes_kernel(const float4* __restric
         for (int i = sub; i < leaf.y; i += 8) {
             float b[3], tp[3];
             if (PRIM == PRIM_SPHERE) sphere_box(prims[leaf.x + i], b, tp);
-            else if (PRIM == PRIM_SPHERE_D4) {
+            else if (PRIM == PRIM_BOX) {
+                const float* q = reinterpret_cast<const float*>(prims) + 6 * size_t(leaf.x + i);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { b[c] = q[c]; tp[c] = q[3 + c]; }
+            } else if (PRIM == PRIM_SPHERE_D4) {
                 // AABBSphere with Real4 = double4 (generic/functors/aabb.h:9-26): centre -+ radius
                 // in double, narrowed to the float corner
                 const double* s = reinterpret_cast<const double*>(prims) + 4 * size_t(leaf.x + i);
@@ -458,6 +468,26 @@ __global__ __launch_bounds__(256) void nodes_direct_kernel(const MaxPyramid<D> m
     }
 }
 
+// DeltaComp = thrust::greater (albvh.cuh:1029-1045 lets the caller choose the comparator; it is
+// only ever applied as delta_comp(delta_L, delta_R), albvh.cuh:129,194,465,607): the build below is
+// written for `<`, and a > b  <=>  flip(a) < flip(b) with flip = negation for floating-point deltas
+// (exact, order-reversing, NaN stays unordered) and bitwise NOT for unsigned ones.
+template <typename D>
+__device__ __forceinline__ D flip_order(const D d)
+{
+    if constexpr (std::is_floating_point<D>::value) return -d;
+    else return ~d;
+}
+
+template <typename D>
+__global__ __launch_bounds__(256) void flip_deltas_kernel(const D* __restrict__ in, size_t n,
+                                                          D* __restrict__ out)
+{
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
+         i += size_t(gridDim.x) * blockDim.x)
+        out[i] = flip_order(in[i]);
+}
+
 // Measurement hook (profile_tree's per-phase lines): HIP events around the leaf stage and the
 // node stage of the last build on its stream.
 bool g_phase_timing = false;
@@ -467,7 +497,7 @@ hipEvent_t g_pe[3] = { nullptr, nullptr, nullptr };
 template <typename D, int PRIM = PRIM_SPHERE>
 grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, int mpl,
                          int* d_nodes, int* d_leaves, int* d_root, size_t* h_n_leaves,
-                         hipStream_t stream)
+                         hipStream_t stream, const bool greater = false)
 {
     GRACE_REQUIRE(d_spheres && d_deltas && d_nodes && d_leaves && d_root && h_n_leaves,
                   "build_ALBVH: null pointer");
@@ -483,8 +513,15 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
     const size_t ws = 3 * Workspace::aligned(n * 4) + Workspace::aligned(scan_ws_count(n) * 4)
         + Workspace::aligned((n + 1) * sizeof(D)) + Workspace::aligned(n * 4)
         + Workspace::aligned(n * 24) + 1024
-        + Workspace::aligned((n / 64 + 8) * 8) + 2 * Workspace::aligned((n / 64 + 8) * 4);
+        + Workspace::aligned((n / 64 + 8) * 8) + 2 * Workspace::aligned((n / 64 + 8) * 4)
+        + (greater ? Workspace::aligned((n + 1) * sizeof(D)) : 0);
     GRACE_TRY(Workspace::begin(ws, stream));
+    if (greater) {
+        D* flipped = Workspace::take<D>(n + 1);
+        flip_deltas_kernel<D><<<stream_grid(n + 1, 256), 256, 0, stream>>>(d_deltas, n + 1, flipped);
+        GRACE_CHECK_LAUNCH();
+        d_deltas = flipped;
+    }
     uint32_t* flags = Workspace::take<uint32_t>(n);
     uint32_t* counts = Workspace::take<uint32_t>(n); // scratch of the pyramids below
     (void)counts;
@@ -628,6 +665,33 @@ GRACE_ALBVH(grace_albvh_build_d4_f64, double, double, PRIM_SPHERE_D4)
 GRACE_ALBVH(grace_albvh_build_d4_u32, double, uint32_t, PRIM_SPHERE_D4)
 GRACE_ALBVH(grace_albvh_build_d4_u64, double, uint64_t, PRIM_SPHERE_D4)
 #undef GRACE_ALBVH
+
+// One entry for every (primitive kind, delta type, comparator) of build_ALBVH
+// (albvh.cuh:986-1072), incl. caller-evaluated boxes and DeltaComp = greater.
+grace_status grace_albvh_build_ex(int prim_kind, const void* d_prims, size_t n, int delta_type,
+                                  const void* d_deltas, int delta_comp, int max_per_leaf,
+                                  int* d_nodes, int* d_leaves, int* d_root, size_t* h_n_leaves,
+                                  grace_stream stream)
+{
+    GRACE_REQUIRE(delta_comp == GRACE_COMP_LESS || delta_comp == GRACE_COMP_GREATER,
+                  "build_ALBVH: delta comparator must be GRACE_COMP_LESS or GRACE_COMP_GREATER");
+    const bool gt = delta_comp == GRACE_COMP_GREATER;
+    const float* p = static_cast<const float*>(d_prims);
+    hipStream_t s = as_stream(stream);
+#define GRACE_EX(K, DT, D)                                                                       \
+    if (prim_kind == K && delta_type == DT)                                                      \
+        return albvh_build<D, K>(p, n, static_cast<const D*>(d_deltas), max_per_leaf, d_nodes,   \
+                                 d_leaves, d_root, h_n_leaves, s, gt);
+#define GRACE_EX_KIND(K)                                                                         \
+    GRACE_EX(K, GRACE_DELTA_F32, float) GRACE_EX(K, GRACE_DELTA_F64, double)                     \
+    GRACE_EX(K, GRACE_DELTA_U32, uint32_t) GRACE_EX(K, GRACE_DELTA_U64, uint64_t)
+    GRACE_EX_KIND(PRIM_SPHERE) GRACE_EX_KIND(PRIM_TRIANGLE) GRACE_EX_KIND(PRIM_SPHERE_D4)
+    GRACE_EX_KIND(PRIM_BOX)
+#undef GRACE_EX_KIND
+#undef GRACE_EX
+    return set_error(GRACE_INVALID_ARGUMENT, __FILE__, __LINE__,
+                     "build_ALBVH: unknown primitive kind or delta type");
+}
 
 grace_status grace_albvh_enable_timing(int enabled)
 {

@@ -9,33 +9,14 @@
 // Algorithmic bytes: 20 B/sphere (30-bit keys), 24 B/sphere (63-bit); bounds pass 16 B/sphere.
 #include "common.hpp"
 
+#include "grace/generic/morton.h"
+
 using namespace grace_hip;
 
 namespace {
 
-__device__ __forceinline__ uint32_t space_by_two_10bit(uint32_t x)
-{
-    x &= (1u << 10) - 1;
-    x = (x | (x << 16)) & 0x030000FFu;
-    x = (x | (x << 8)) & 0x0300F00Fu;
-    x = (x | (x << 4)) & 0x030C30C3u;
-    x = (x | (x << 2)) & 0x09249249u;
-    return x;
-}
-
-__device__ __forceinline__ uint64_t space_by_two_21bit(uint64_t x)
-{
-    // Magic numbers as in the reference (generic/bits.h:35-46), pinned by its 63-bit
-    // known-answer test.
-    x &= (1u << 21) - 1;
-    x = (x | x << 32) & 0x001f00000000ffffull;
-    x = (x | x << 16) & 0x001f0000ff0000ffull;
-    x = (x | x << 8) & 0x100f00f00f00f00full;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-    x = (x | x << 2) & 0x1249249249249249ull;
-    return x;
-}
-
+// The key arithmetic itself is the product header's (include/grace/generic/{bits,morton}.h:
+// host- and device-callable, pinned by the reference's known-answer tests).
 template <typename Key>
 struct Interleave;
 
@@ -43,7 +24,7 @@ template <>
 struct Interleave<uint32_t> {
     static __device__ __forceinline__ uint32_t key(uint32_t x, uint32_t y, uint32_t z)
     {
-        return space_by_two_10bit(z) << 2 | space_by_two_10bit(y) << 1 | space_by_two_10bit(x);
+        return grace::morton_key(x, y, z);
     }
 };
 
@@ -51,7 +32,7 @@ template <>
 struct Interleave<uint64_t> {
     static __device__ __forceinline__ uint64_t key(uint64_t x, uint64_t y, uint64_t z)
     {
-        return space_by_two_21bit(z) << 2 | space_by_two_21bit(y) << 1 | space_by_two_21bit(x);
+        return grace::morton_key(x, y, z);
     }
 };
 

@@ -430,9 +430,10 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ v,
         v[i] = value;
 }
 
+template <typename Real>
 __global__ __launch_bounds__(256) void multiply_by_weights_kernel(
-    const float* __restrict__ x, size_t n, const float* __restrict__ w,
-    const uint32_t* __restrict__ map, float* __restrict__ out)
+    const Real* __restrict__ x, size_t n, const Real* __restrict__ w,
+    const uint32_t* __restrict__ map, Real* __restrict__ out)
 {
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n;
          i += size_t(gridDim.x) * blockDim.x)
@@ -530,7 +531,20 @@ grace_status grace_multiply_by_weights_f32(const float* d_unweighted, size_t n,
     GRACE_REQUIRE(n == 0 || (d_unweighted && d_weights && d_weight_map && d_weighted),
                   "multiply_by_weights: null pointer");
     if (n == 0) return GRACE_OK;
-    multiply_by_weights_kernel<<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
+    multiply_by_weights_kernel<float><<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
+        d_unweighted, n, d_weights, d_weight_map, d_weighted);
+    GRACE_CHECK_LAUNCH();
+    return GRACE_OK;
+}
+
+grace_status grace_multiply_by_weights_f64(const double* d_unweighted, size_t n,
+                                           const double* d_weights, const uint32_t* d_weight_map,
+                                           double* d_weighted, grace_stream stream)
+{
+    GRACE_REQUIRE(n == 0 || (d_unweighted && d_weights && d_weight_map && d_weighted),
+                  "multiply_by_weights: null pointer");
+    if (n == 0) return GRACE_OK;
+    multiply_by_weights_kernel<double><<<stream_grid(n, 256), 256, 0, as_stream(stream)>>>(
         d_unweighted, n, d_weights, d_weight_map, d_weighted);
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;

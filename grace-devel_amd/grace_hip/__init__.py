@@ -218,6 +218,44 @@ def ALBVH_sph(spheres, deltas, tree):
     return tree
 
 
+PRIM_SPHERE_F4, PRIM_TRIANGLE, PRIM_SPHERE_D4, PRIM_BOX = 0, 1, 2, 3
+COMP_LESS, COMP_GREATER = 0, 1
+_DELTA_CODES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3}
+
+
+def build_ALBVH(tree, prims, deltas, prim_kind=PRIM_SPHERE_F4, delta_comp=COMP_LESS):
+    """The generic grace::build_ALBVH forms (kernels/albvh.cuh:986-1072) through
+    grace_albvh_build_ex: prims are float4 / double4 spheres, triangles [n, 9], or -- PRIM_BOX --
+    the caller's AABB functor already evaluated, [n, 6] floats {bot xyz, top xyz}; DeltaComp is
+    thrust::less (default) or thrust::greater."""
+    n = len(prims)
+    assert tree.leaves.shape[0] >= n and len(deltas) == n + 1
+    if deltas.dtype not in _DELTA_CODES:
+        raise ValueError("deltas must be float32/float64 or 32/64-bit XOR deltas")
+    n_leaves = C.c_size_t(0)
+    _check(_lib.grace_albvh_build_ex(C.c_int(prim_kind), _ptr(prims), C.c_size_t(n),
+                                     C.c_int(_DELTA_CODES[deltas.dtype]), _ptr(deltas), C.c_int(delta_comp),
+                                     C.c_int(tree.max_per_leaf), _ptr(tree.nodes), _ptr(tree.leaves),
+                                     _ptr(tree.root_index), C.byref(n_leaves), _stream()))
+    tree.leaves = tree.leaves[: n_leaves.value]
+    tree.nodes = tree.nodes[: n_leaves.value - 1]
+    return tree
+
+
+def min_max_components(data, n_comp, first=0):
+    """grace::min_max_x/y/z/w, min/max_vec2/3/4 (util/extrema.cuh:190-772): minima and maxima of
+    components first .. first + n_comp - 1 of the rows of a 2-D float32 / float64 / int32 tensor."""
+    code = {torch.float32: 0, torch.float64: 1, torch.int32: 2}[data.dtype]
+    assert data.dim() == 2 and data.is_contiguous() and first + n_comp <= data.shape[1]
+    npdt = {0: np.float32, 1: np.float64, 2: np.int32}[code]
+    lo = np.zeros(n_comp, npdt); hi = np.zeros(n_comp, npdt)
+    elem = data.element_size()
+    _check(_lib.grace_minmax_components(C.c_void_p(data.data_ptr() + first * elem), C.c_size_t(len(data)),
+                                        C.c_int(code), C.c_int(n_comp), C.c_size_t(data.shape[1] * elem),
+                                        lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), _stream()))
+    return lo, hi
+
+
 def build_tree(spheres, tree, low=None, high=None):
     """tests/helper/tree.cuh:15-43: 30-bit keys, Euclidean deltas, sorts spheres in place."""
     deltas = torch.empty(len(spheres) + 1, dtype=torch.float32, device=spheres.device)
@@ -511,9 +549,9 @@ def sort_by_distance(hit_distances, ray_offsets, hit_indices, hit_data):
 def weighted_exclusive_segmented_scan(to_sum, weights, weight_map, segment_offsets, out):
     """scan.cuh:43-58."""
     weighted = torch.empty_like(to_sum)
-    _check(_lib.grace_multiply_by_weights_f32(_ptr(to_sum), C.c_size_t(len(to_sum)),
-                                              _ptr(weights), _ptr(weight_map), _ptr(weighted),
-                                              _stream()))
+    fn = _lib.grace_multiply_by_weights_f64 if to_sum.dtype == torch.float64 else _lib.grace_multiply_by_weights_f32
+    _check(fn(_ptr(to_sum), C.c_size_t(len(to_sum)),
+              _ptr(weights), _ptr(weight_map), _ptr(weighted), _stream()))
     return exclusive_segmented_scan(segment_offsets, weighted, out)
 
 

@@ -14,6 +14,10 @@ inline void segscan_dispatch(const int* off, size_t ns, const float* d, size_t n
 { GRACE_STATUS_CHECK(grace_segscan_exclusive_f32(off, ns, d, n, r, NULL)); }
 inline void segscan_dispatch(const int* off, size_t ns, const double* d, size_t n, double* r)
 { GRACE_STATUS_CHECK(grace_segscan_exclusive_f64(off, ns, d, n, r, NULL)); }
+inline void weights_dispatch(const float* x, size_t n, const float* w, const unsigned int* m, float* out)
+{ GRACE_STATUS_CHECK(grace_multiply_by_weights_f32(x, n, w, m, out, NULL)); }
+inline void weights_dispatch(const double* x, size_t n, const double* w, const unsigned int* m, double* out)
+{ GRACE_STATUS_CHECK(grace_multiply_by_weights_f64(x, n, w, m, out, NULL)); }
 } // namespace detail
 
 // d_data and d_results may be the same vector.
@@ -29,17 +33,18 @@ GRACE_HOST void exclusive_segmented_scan(
 
 // weighted_values[i] = d_to_sum[i] * d_weights[d_weight_map[i]], then the exclusive segmented
 // sum of the weighted values (scan.cuh:39-58; kernels/weights.cuh:13-27).
+// Real: float or double.
+template <typename Real>
 GRACE_HOST void weighted_exclusive_segmented_scan(
-    const thrust::device_vector<float>& d_to_sum,
-    const thrust::device_vector<float>& d_weights,
+    const thrust::device_vector<Real>& d_to_sum,
+    const thrust::device_vector<Real>& d_weights,
     const thrust::device_vector<unsigned int>& d_weight_map,
     const thrust::device_vector<int>& d_segment_offsets,
-    thrust::device_vector<float>& d_sum)
+    thrust::device_vector<Real>& d_sum)
 {
-    thrust::device_vector<float> d_weighted(d_to_sum.size());
-    GRACE_STATUS_CHECK(grace_multiply_by_weights_f32(detail::raw(d_to_sum), d_to_sum.size(),
-                                                     detail::raw(d_weights), detail::raw(d_weight_map),
-                                                     detail::raw(d_weighted), NULL));
+    thrust::device_vector<Real> d_weighted(d_to_sum.size());
+    detail::weights_dispatch(detail::raw(d_to_sum), d_to_sum.size(), detail::raw(d_weights),
+                             detail::raw(d_weight_map), detail::raw(d_weighted));
     grace::exclusive_segmented_scan(d_segment_offsets, d_weighted, d_sum);
 }
 

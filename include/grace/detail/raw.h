@@ -15,6 +15,13 @@ inline T* raw(thrust::device_vector<T>& v) { return thrust::raw_pointer_cast(v.d
 template <typename T>
 inline const T* raw(const thrust::device_vector<T>& v) { return thrust::raw_pointer_cast(v.data()); }
 
+// Raw device pointer behind an iterator: a plain pointer, or a Thrust device iterator /
+// device_ptr over contiguous storage.
+template <typename T>
+inline T* raw_of(T* p) { return p; }
+template <typename Iter>
+inline auto raw_of(Iter it) -> decltype(thrust::raw_pointer_cast(&*it)) { return thrust::raw_pointer_cast(&*it); }
+
 template <typename T> struct always_false { static const bool value = false; };
 
 template <typename Real4> struct is_float4 { static const bool value = false; };

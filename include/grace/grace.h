@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "grace_hip.h"
+#include "grace/generic/morton.h"   // host-callable grace::morton_key, detail::space_by_two_* (generic/morton.h:14-55)
 #include "grace/ray.h"   // grace::Ray (include/grace/ray.h:5-10)
 
 namespace grace {

@@ -14,20 +14,11 @@
 #endif
 #define GRACE_DROPIN_HEADERS_INCLUDED 1
 
-#include <stdint.h>
+#include "grace/detail/config.h"   // GRACE_HOST / _DEVICE / _HOST_DEVICE, uinteger32/64, integer32/64
 
 #include <hip/hip_runtime.h>   // float4, int4, double4, make_float3 ... (vector_types.h in the reference)
 
-#define GRACE_HOST __host__ inline
-#define GRACE_DEVICE __device__ inline
-#define GRACE_HOST_DEVICE __host__ __device__ inline
-
 namespace grace {
-
-typedef uint32_t uinteger32;
-typedef uint64_t uinteger64;
-typedef int32_t integer32;
-typedef int64_t integer64;
 
 // Binary encoding with +ve = 1, -ve = 0: octants for ray generation (types.h:36-45).
 enum Octants { PPP = 7, PPM = 6, PMP = 5, PMM = 4, MPP = 3, MPM = 2, MMP = 1, MMM = 0 };

@@ -74,6 +74,14 @@ grace_status grace_centroid_bounds_f4(const float* d_spheres, size_t n,
  * tests/project_gadget/project_gadget.cu:66-68).  Synchronises. */
 grace_status grace_minmax_f4(const float* d_v4, size_t n, float* h_mins4, float* h_maxs4,
                              grace_stream stream);
+/* The rest of include/grace/cuda/util/extrema.cuh:190-772 (min_max_x/y/z/w, min/max_vec2/3/4 over
+ * any vector type): component-wise minima and maxima of n records of n_comp (1..4) leading
+ * components of elem_type, stride_bytes apart.  h_mins / h_maxs: host arrays of n_comp elements
+ * of the same type.  Synchronises. */
+enum { GRACE_ELEM_F32 = 0, GRACE_ELEM_F64 = 1, GRACE_ELEM_I32 = 2, GRACE_ELEM_U32 = 3 };
+grace_status grace_minmax_components(const void* d_data, size_t n, int elem_type, int n_comp,
+                                     size_t stride_bytes, void* h_mins, void* h_maxs,
+                                     grace_stream stream);
 /* grace::morton_keys(prims, N, bot, top, keys, CentroidSphere) with uinteger32 keys and
  * Real3 = float3 (include/grace/cuda/kernels/morton.cuh:97-119,30-55; build_sph.cuh:27-35). */
 grace_status grace_morton_keys30_f4(const float* d_spheres, size_t n, const float* h_bot,
@@ -172,6 +180,21 @@ grace_status grace_morton_keys30_tri(const float* d_tris, size_t n, const float*
 grace_status grace_albvh_build_tri_u32(const float* d_tris, size_t n, const uint32_t* d_deltas,
                                        int max_per_leaf, int* d_nodes, int* d_leaves, int* d_root,
                                        size_t* h_n_leaves, grace_stream stream);
+
+/* ---- the generic forms of grace/cuda/kernels/albvh.cuh:986-1072 in one entry: any primitive kind
+ *      (float4 / double4 spheres with AABBSphere, the shipped triangles, or GRACE_PRIM_BOX: the
+ *      caller's own AABBFunc already evaluated per primitive -- 6 floats {bot xyz, top xyz} each,
+ *      written by the header kernel of include/grace/cuda/kernels/albvh.cuh, which runs the functor
+ *      in the caller's translation unit), any delta type, and DeltaComp = thrust::less or
+ *      thrust::greater (albvh.cuh:1029-1045; the comparator is only ever applied as
+ *      delta_comp(delta_L, delta_R), albvh.cuh:129,194,465,607). -------------------------------- */
+enum { GRACE_PRIM_SPHERE_F4 = 0, GRACE_PRIM_TRIANGLE = 1, GRACE_PRIM_SPHERE_D4 = 2, GRACE_PRIM_BOX = 3 };
+enum { GRACE_DELTA_F32 = 0, GRACE_DELTA_F64 = 1, GRACE_DELTA_U32 = 2, GRACE_DELTA_U64 = 3 };
+enum { GRACE_COMP_LESS = 0, GRACE_COMP_GREATER = 1 };
+grace_status grace_albvh_build_ex(int prim_kind, const void* d_prims, size_t n, int delta_type,
+                                  const void* d_deltas, int delta_comp, int max_per_leaf,
+                                  int* d_nodes, int* d_leaves, int* d_root, size_t* h_n_leaves,
+                                  grace_stream stream);
 
 /* Measurement hook for profile_tree-style harnesses (tests/profile_tree/profile_tree.cu prints
  * one line per build phase): when enabled, HIP events are recorded on the build's stream around
@@ -337,6 +360,10 @@ grace_status grace_fill_u32(void* d_values, size_t n, uint32_t bits, grace_strea
 grace_status grace_multiply_by_weights_f32(const float* d_unweighted, size_t n,
                                            const float* d_weights, const uint32_t* d_weight_map,
                                            float* d_weighted, grace_stream stream);
+/* ... with Real = double (scan.cuh:43-58 is a template on Real). */
+grace_status grace_multiply_by_weights_f64(const double* d_unweighted, size_t n,
+                                           const double* d_weights, const uint32_t* d_weight_map,
+                                           double* d_weighted, grace_stream stream);
 
 /* ---- per-ray sort of hits by distance: grace::sort_by_distance
  *      (include/grace/cuda/sort.cuh:100-131): within each ray's segment distances become

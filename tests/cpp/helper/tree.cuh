@@ -1,6 +1,7 @@
-// helper/tree.cuh -- build_tree / random_spheres_tree as the reference's tests compose them
-// from the library API (tests/helper/tree.cuh:13-60): 30-bit keys + sort, Euclidean deltas,
-// ALBVH.
+// helper/tree.cuh -- build_tree / random_spheres_tree for the test programs: sort the spheres
+// along the 30-bit Morton curve (inside the given box, or inside the box of their centres), take
+// the Euclidean deltas of neighbours, build the ALBVH -- the composition the reference's tests
+// use (tests/helper/tree.cuh), written against the drop-in API.
 #pragma once
 
 #include "grace/cuda/build_sph.cuh"
@@ -11,29 +12,31 @@
 
 #include <thrust/device_vector.h>
 
-// Always uses 30-bit keys.
+namespace helper_detail {
+template <typename Real4>
+inline void deltas_and_tree(const thrust::device_vector<Real4>& sorted_spheres, grace::Tree& tree)
+{
+    thrust::device_vector<typename grace::Real4ToRealMapper<Real4>::type> deltas(sorted_spheres.size() + 1);
+    grace::euclidean_deltas_sph(sorted_spheres, deltas);
+    grace::ALBVH_sph(sorted_spheres, deltas, tree);
+}
+} // namespace helper_detail
+
 template <typename Real4>
 void build_tree(thrust::device_vector<Real4>& spheres, grace::Tree& tree)
 {
-    typedef typename grace::Real4ToRealMapper<Real4>::type Real;
-    thrust::device_vector<Real> deltas(spheres.size() + 1);
     grace::morton_keys30_sort_sph(spheres);
-    grace::euclidean_deltas_sph(spheres, deltas);
-    grace::ALBVH_sph(spheres, deltas, tree);
+    helper_detail::deltas_and_tree(spheres, tree);
 }
 
-// low and high can be any type with .x/.y/.z components.
+// low / high: anything with .x, .y, .z (the key arithmetic runs in float).
 template <typename Real3, typename Real4>
 void build_tree(thrust::device_vector<Real4>& spheres, const Real3 low, const Real3 high,
                 grace::Tree& tree)
 {
-    typedef typename grace::Real4ToRealMapper<Real4>::type Real;
-    const float3 bottom = make_float3(low.x, low.y, low.z);
-    const float3 top = make_float3(high.x, high.y, high.z);
-    thrust::device_vector<Real> deltas(spheres.size() + 1);
-    grace::morton_keys30_sort_sph(spheres, bottom, top);
-    grace::euclidean_deltas_sph(spheres, deltas);
-    grace::ALBVH_sph(spheres, deltas, tree);
+    grace::morton_keys30_sort_sph(spheres, make_float3(low.x, low.y, low.z),
+                                  make_float3(high.x, high.y, high.z));
+    helper_detail::deltas_and_tree(spheres, tree);
 }
 
 template <typename Real4>

@@ -60,7 +60,8 @@ def test_reference_header_paths_compile_with_hipcc(tmp_path):
     """The drop-in header set (include/grace/cuda/*.cuh, nodes.h, ray.h, types.h ... over
     thrust::device_vector) compiles for gfx950 with hipcc: three callers written against the
     reference's include lines (run on the GPU by tests/test_gpu_dropin.py)."""
-    for name in ("dropin_project_gadget", "dropin_tree_traversal", "dropin_types"):
+    for name in ("dropin_project_gadget", "dropin_tree_traversal", "dropin_types", "dropin_triangles",
+                 "dropin_generic"):
         exe = tmp_path / name
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17",
                                "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
@@ -69,6 +70,40 @@ def test_reference_header_paths_compile_with_hipcc(tmp_path):
                                "-L" + os.path.dirname(LIB), "-lgrace_hip",
                                "-Wl,-rpath," + os.path.dirname(LIB)])
         assert exe.exists()
+
+
+def test_host_morton_key_known_answers(tmp_path, oracle):
+    """BASELINE config 1 (tests/morton_key: the CPU host path) on the PRODUCT headers
+    include/grace/generic/{bits,morton}.h, built with plain g++: the reference's own known-answer
+    vectors (tests/golden/kat.json <- tests/morton_key/30bit_key.cu:20-26, 63bit_key.cu:20-26),
+    and the float / double forms against the oracle's keys on random points."""
+    import json
+    exe = str(tmp_path / "morton_key_kat")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "morton_key_kat.cpp"), "-o", exe])
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
+    for bits in ("30", "63"):
+        k = kat["morton" + bits]
+        out = subprocess.check_output([exe, bits, str(k["x"]), str(k["y"]), str(k["z"])], text=True).split()
+        assert [int(v) for v in out] == [k["spaced_x"], k["spaced_y"], k["spaced_z"], k["key"]]
+    # high bits beyond 10 / 21 are masked away (generic/bits.h:27,38)
+    out = subprocess.check_output([exe, "30", str(309 + 1024 * 5), "942", "619"], text=True).split()
+    assert int(out[3]) == kat["morton30"]["key"]
+    rng = np.random.default_rng(5)
+    pts = rng.random((64, 3))
+    p4 = np.concatenate([pts, np.zeros((64, 1))], 1).astype(np.float32)
+    ref30 = oracle.morton_keys30(p4, (0, 0, 0), (1, 1, 1))
+    for i in range(64):
+        x, y, z = (repr(float(v)) for v in p4[i, :3])
+        assert int(subprocess.check_output([exe, "f", x, y, z], text=True)) == int(ref30[i])
+    # morton_key(double, double, double): span * x in double, truncated, interleaved -- against
+    # Python integers
+    def spread(v, n):
+        return sum(((v >> b) & 1) << (3 * b) for b in range(n))
+    for i in range(16):
+        x, y, z = (float(v) for v in pts[i])
+        want = (spread(int(2097151 * z), 21) << 2) | (spread(int(2097151 * y), 21) << 1) | spread(int(2097151 * x), 21)
+        assert int(subprocess.check_output([exe, "d", repr(x), repr(y), repr(z)], text=True)) == want
 
 
 def test_product_path_does_not_touch_the_oracle():

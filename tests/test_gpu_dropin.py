@@ -17,10 +17,10 @@ LIBDIR = os.path.join(ROOT, "grace-devel_amd", "lib")
 pytestmark = pytest.mark.gpu
 
 
-def build_dropin(tmp_path, name):
-    exe = str(tmp_path / name)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17",
-                           "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+def build_dropin(tmp_path, name, flags=("-ffp-contract=off",), suffix=""):
+    exe = str(tmp_path / (name + suffix))
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", *flags,
+                           "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "tests", "cpp"),
                            os.path.join(ROOT, "tests", "cpp", name + ".hip"), "-o", exe,
                            "-L" + LIBDIR, "-lgrace_hip", "-Wl,-rpath," + LIBDIR])
@@ -86,3 +86,54 @@ def test_remaining_instantiations_through_reference_headers(tmp_path):
     exe = build_dropin(tmp_path, "dropin_types")
     r = subprocess.run([exe, "60000", "40"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("PASSED"), r.stdout + r.stderr
+
+
+def test_generic_forms_through_reference_headers(tmp_path):
+    """grace::morton_keys / compute_deltas / build_ALBVH with stock and caller-defined functors,
+    thrust::greater, min_max_x/y/z/w, min/max_vec2/3/4, weighted_exclusive_segmented_scan<double>
+    (tests/cpp/dropin_generic.hip): every generic form equals the sphere-specialised one / a host
+    loop, bit for bit.  Built twice: with the test suite's -ffp-contract=off and with hipcc's
+    default (contraction on) -- the stock functors pin their own arithmetic."""
+    for flags, suffix in ((("-ffp-contract=off",), ""), ((), "_default_flags")):
+        exe = build_dropin(tmp_path, "dropin_generic", flags, suffix)
+        r = subprocess.run([exe, "70000"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("PASSED"), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("variant", ["less", "greater", "thrust_sort"])
+def test_caller_defined_triangles_through_generic_forms(tmp_path, gh, cuda, variant):
+    """BASELINE config 5's call sequence (tests/profile_trace_triangle/tris_tree.cuh:17-30,
+    tris_trace.cu:43-62) with the CALLER's primitive and functors (tests/cpp/dropin_triangles.hip):
+    morton_keys(TriCentre) -> sort -> compute_deltas(DeltaXOR) -> build_ALBVH(TriBox) ->
+    trace_texref(HitTri, KeepTri, StartRay, RayExit_to_array).  Sorted primitives, tree and closest
+    hits equal the library's built-in triangle path (grace_*_tri, the ctypes path) bit for bit."""
+    import torch
+    from test_gpu_triangles import heightfield_mesh, _cameras
+    tris = heightfield_mesh(96, 64)
+    tris[:300, 2] = 0.25; tris[:300, 5] = 0.0; tris[:300, 8] = 0.0      # some faces flat in z
+    d = torch.from_numpy(np.ascontiguousarray(tris)).to(cuda)
+    mpl = 8
+    tree = gh.Tree(len(tris), mpl, device=cuda)
+    bot, top = gh.build_tree_tris(d, tree)
+    cams, look_at, up, fovy, length = _cameras(bot.astype(np.float64), top.astype(np.float64), 50., 64, 64)
+    rays = torch.cat([gh.pinhole_camera_rays(64, 64, cam, look_at, up, fovy, length, device=cuda) for cam in cams])
+    out = torch.empty(len(rays), dtype=torch.int32, device=cuda)
+    gh.trace_closest_tri(rays, d, tree, out)
+    gh.trace_status()
+
+    tris.tofile(str(tmp_path / "tris.f32"))
+    rays.cpu().numpy().tofile(str(tmp_path / "rays.f32"))
+    flags = ("-ffp-contract=off", "-DUSE_THRUST_SORT") if variant == "thrust_sort" else ("-ffp-contract=off",)
+    exe = build_dropin(tmp_path, "dropin_triangles", flags, "_" + variant)
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([exe, str(tmp_path / "tris.f32"), str(tmp_path / "rays.f32"), str(mpl), prefix]
+                       + (["greater"] if variant == "greater" else []), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(prefix + ".bounds", np.float32), np.concatenate([bot, top]))
+    assert np.array_equal(np.fromfile(prefix + ".tris", np.float32).reshape(-1, 9), d.cpu().numpy())
+    assert np.array_equal(np.fromfile(prefix + ".leaves", np.int32).reshape(-1, 4), tree.leaves.cpu().numpy())
+    assert np.array_equal(np.fromfile(prefix + ".nodes", np.int32).reshape(-1, 16), tree.nodes.cpu().numpy())
+    assert int(np.fromfile(prefix + ".root", np.int32)[0]) == int(tree.root_index.item())
+    got = np.fromfile(prefix + ".closest", np.int32)
+    assert np.array_equal(got, out.cpu().numpy())
+    assert (got >= 0).sum() > len(got) // 4
