@@ -490,9 +490,7 @@ __global__ __launch_bounds__(256) void flip_deltas_kernel(const D* __restrict__ 
 
 // Measurement hook (profile_tree's per-phase lines): HIP events around the leaf stage and the
 // node stage of the last build on its stream.
-bool g_phase_timing = false;
-bool g_phase_valid = false;
-hipEvent_t g_pe[3] = { nullptr, nullptr, nullptr };
+// (they live in the calling thread's Context: phase_timing, phase_valid, phase_events)
 
 template <typename D, int PRIM = PRIM_SPHERE>
 grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, int mpl,
@@ -515,7 +513,8 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
         + Workspace::aligned(n * 24) + 1024
         + Workspace::aligned((n / 64 + 8) * 8) + 2 * Workspace::aligned((n / 64 + 8) * 4)
         + (greater ? Workspace::aligned((n + 1) * sizeof(D)) : 0);
-    GRACE_TRY(Workspace::begin(ws, stream));
+    FrameGuard frame;
+    GRACE_TRY(frame.begin(ws, stream));
     if (greater) {
         D* flipped = Workspace::take<D>(n + 1);
         flip_deltas_kernel<D><<<stream_grid(n + 1, 256), 256, 0, stream>>>(d_deltas, n + 1, flipped);
@@ -532,11 +531,12 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
     uint32_t* d_total = Workspace::take<uint32_t>(1);
     float* boxes = Workspace::take<float>(6 * n);
 
-    if (g_phase_timing) {
-        for (auto& e : g_pe)
+    Context& ctx = *Workspace::frame_context();
+    if (ctx.phase_timing) {
+        for (auto& e : ctx.phase_events)
             if (!e) GRACE_TRY_HIP(hipEventCreate(&e));
-        g_phase_valid = false;
-        GRACE_TRY_HIP(hipEventRecord(g_pe[0], stream));
+        ctx.phase_valid = false;
+        GRACE_TRY_HIP(hipEventRecord(ctx.phase_events[0], stream));
     }
     const int grid = ceil_div(n, 256);
     if (mpl <= LEAF_FAST_MAX_MPL) {
@@ -564,7 +564,7 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
                                                          reinterpret_cast<int4*>(d_leaves), leaf_ds);
         GRACE_CHECK_LAUNCH();
     }
-    if (g_phase_timing) GRACE_TRY_HIP(hipEventRecord(g_pe[1], stream));
+    if (ctx.phase_timing) GRACE_TRY_HIP(hipEventRecord(ctx.phase_events[1], stream));
     uint32_t n_leaves = 0;
     GRACE_TRY_HIP(hipMemcpyAsync(&n_leaves, d_total, 4, hipMemcpyDeviceToHost, stream));
     GRACE_TRY_HIP(hipStreamSynchronize(stream));
@@ -605,9 +605,9 @@ grace_status albvh_build(const float* d_spheres, size_t n, const D* d_deltas, in
     nodes_direct_kernel<D><<<ceil_div(size_t(n_nodes) + n_leaves, 256), 256, 0, stream>>>(
         mp, bp, leaf_ds, int(n_leaves), d_nodes, d_root);
     GRACE_CHECK_LAUNCH();
-    if (g_phase_timing) {
-        GRACE_TRY_HIP(hipEventRecord(g_pe[2], stream));
-        g_phase_valid = true;
+    if (ctx.phase_timing) {
+        GRACE_TRY_HIP(hipEventRecord(ctx.phase_events[2], stream));
+        ctx.phase_valid = true;
     }
     return GRACE_OK;
 }
@@ -695,18 +695,22 @@ grace_status grace_albvh_build_ex(int prim_kind, const void* d_prims, size_t n, 
 
 grace_status grace_albvh_enable_timing(int enabled)
 {
-    g_phase_timing = enabled != 0;
-    if (!g_phase_timing) g_phase_valid = false;
+    Context* ctx = nullptr;
+    GRACE_TRY(current_context(&ctx));
+    ctx->phase_timing = enabled != 0;
+    if (!ctx->phase_timing) ctx->phase_valid = false;
     return GRACE_OK;
 }
 
 grace_status grace_albvh_last_phase_ms(float* h_leaves_ms, float* h_nodes_ms)
 {
     GRACE_REQUIRE(h_leaves_ms && h_nodes_ms, "albvh_last_phase_ms: null pointer");
-    GRACE_REQUIRE(g_phase_timing && g_phase_valid, "no timed ALBVH build recorded");
-    GRACE_TRY_HIP(hipEventSynchronize(g_pe[2]));
-    GRACE_TRY_HIP(hipEventElapsedTime(h_leaves_ms, g_pe[0], g_pe[1]));
-    GRACE_TRY_HIP(hipEventElapsedTime(h_nodes_ms, g_pe[1], g_pe[2]));
+    Context* ctx = nullptr;
+    GRACE_TRY(current_context(&ctx));
+    GRACE_REQUIRE(ctx->phase_timing && ctx->phase_valid, "no timed ALBVH build recorded");
+    GRACE_TRY_HIP(hipEventSynchronize(ctx->phase_events[2]));
+    GRACE_TRY_HIP(hipEventElapsedTime(h_leaves_ms, ctx->phase_events[0], ctx->phase_events[1]));
+    GRACE_TRY_HIP(hipEventElapsedTime(h_nodes_ms, ctx->phase_events[1], ctx->phase_events[2]));
     return GRACE_OK;
 }
 

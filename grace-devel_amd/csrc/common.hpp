@@ -40,32 +40,83 @@ grace_status set_error(grace_status code, const char* file, int line, const char
 
 inline hipStream_t as_stream(grace_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Bump allocator over the library's grow-only workspace.  A call opens a frame, carves
-// its temporaries, and the frame is implicitly dropped at the next call (stream order
-// keeps earlier kernels safe because every entry point runs on one stream at a time).
+// ---- library state -----------------------------------------------------------------------------
+// Everything the library keeps between calls lives in a Context: the grow-only workspace, the
+// traversal's status word / cached scene and ray order / tuning knobs / timing events
+// (TraceState, csrc/trace_state.hpp) and the build's phase events.  A context belongs to ONE
+// device.  Every device has a default context, created on first use; a thread that wants state of
+// its own -- several host threads driving one GPU, or one thread per GPU of a node in a single
+// process (the reference's ncclCommInitAll shape) -- creates contexts with
+// grace_context_create and makes one current for itself (grace_context_set_current, thread-local).
+// A context serves one call at a time: two threads may run concurrently iff their current
+// contexts differ.
+struct TraceState;
+struct Context {
+    int device = -1;
+    // workspace: one device buffer, bump-allocated per call ("frame")
+    char* ws_base = nullptr;
+    size_t ws_capacity = 0, ws_used = 0;
+    // recorded on a frame's own stream when the frame closes; a frame opened on ANOTHER stream
+    // waits for it (frames alias).  No stream handle is ever kept: a caller may destroy its stream
+    // between calls.
+    hipEvent_t ws_fence = nullptr;
+    bool ws_fence_valid = false;
+    hipStream_t ws_fence_stream = nullptr;   // compared only, never dereferenced
+    bool ws_frame_open = false;
+    // ALBVH phase timing (grace_albvh_enable_timing)
+    bool phase_timing = false, phase_valid = false;
+    hipEvent_t phase_events[3] = { nullptr, nullptr, nullptr };
+    // traversal state, owned by the trace translation units
+    TraceState* trace = nullptr;
+};
+
+// The calling thread's context: the one it made current, else the current device's default
+// context.  Fails if the thread's explicit context belongs to another device than the current one.
+grace_status current_context(Context** out);
+// Registered by the trace translation unit: frees a context's TraceState (device buffers, events).
+extern grace_status (*g_trace_state_destroy)(Context&);
+
+// Bump allocator over the current context's workspace.  A call opens a frame (FrameGuard below),
+// carves its temporaries, and the frame's memory is reused by the next call on the context; stream
+// order keeps earlier kernels safe, and a frame opened on another stream than the previous one first
+// waits (device side) for the event the previous frame recorded when it closed.
 class Workspace {
 public:
-    // Makes sure `bytes` are available and resets the bump pointer.  `stream` is the stream the
-    // call's kernels run on: a frame opened on another stream than the previous one first waits
-    // (device side) for everything the previous frame's stream has been given, since the two
-    // frames share the same memory.
-    static grace_status begin(size_t bytes, hipStream_t stream);
     template <typename T>
     static T* take(size_t count)
     {
+        Context& c = *frame_context();
         size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
-        char* p = base_ + used_;
-        used_ += bytes;
+        char* p = c.ws_base + c.ws_used;
+        c.ws_used += bytes;
         return reinterpret_cast<T*>(p);
     }
     static size_t aligned(size_t bytes) { return (bytes + 255) & ~size_t(255); }
     static grace_status reserve(size_t bytes);
     static grace_status release();
+    // (use FrameGuard; these are its two halves)
+    static grace_status begin(size_t bytes, hipStream_t stream);
+    static void end(hipStream_t stream);
+    static Context* frame_context();    // the context of the calling thread's open frame
+};
 
+// Scope of one call's workspace frame: begin() makes `bytes` available on the calling thread's
+// context and resets the bump pointer; leaving the scope records the context's fence on `stream`.
+class FrameGuard {
+public:
+    FrameGuard() = default;
+    FrameGuard(const FrameGuard&) = delete;
+    FrameGuard& operator=(const FrameGuard&) = delete;
+    grace_status begin(size_t bytes, hipStream_t stream)
+    {
+        grace_status s = Workspace::begin(bytes, stream);
+        if (s == GRACE_OK) { open_ = true; stream_ = stream; }
+        return s;
+    }
+    ~FrameGuard() { if (open_) Workspace::end(stream_); }
 private:
-    static char* base_;
-    static size_t capacity_;
-    static size_t used_;
+    bool open_ = false;
+    hipStream_t stream_ = nullptr;
 };
 
 constexpr int WAVE = 64;

@@ -2,6 +2,7 @@
 #include "common.hpp"
 
 #include <cstring>
+#include <mutex>
 
 namespace grace_hip {
 
@@ -15,69 +16,136 @@ grace_status set_error(grace_status code, const char* file, int line, const char
     return code;
 }
 
-char* Workspace::base_ = nullptr;
-size_t Workspace::capacity_ = 0;
-size_t Workspace::used_ = 0;
+// ---- contexts ----------------------------------------------------------------------------------
+constexpr int MAX_DEVICES = 64;
+static Context* g_default_context[MAX_DEVICES] = {};
+static std::mutex g_context_mutex;                    // guards creation / destruction only
+static thread_local Context* t_current = nullptr;     // the thread's explicit context, if any
+static thread_local Context* t_frame = nullptr;       // context of the thread's open frame
 
-// The workspace (like the status word, the prepared scene and the tuning knobs) is
-// process-global: one device, one stream at a time -- the shape of one process per GPU.  A call
-// made with another device current would get pointers into the first device's memory: refuse it.
-static int g_owner_device = -1;
+grace_status (*g_trace_state_destroy)(Context&) = nullptr;
 
-grace_status Workspace::reserve(size_t bytes)
+grace_status current_context(Context** out)
 {
     int dev = -1;
     GRACE_TRY_HIP(hipGetDevice(&dev));
-    if (g_owner_device < 0) g_owner_device = dev;
-    if (dev != g_owner_device)
-        return set_error(GRACE_INVALID_ARGUMENT, __FILE__, __LINE__,
-                         "libgrace_hip.so serves one device per process (its workspace lives on the "
-                         "device of the first call): run one process per GPU");
-    if (bytes <= capacity_) return GRACE_OK;
+    if (t_current) {
+        if (t_current->device != dev)
+            return set_error(GRACE_INVALID_ARGUMENT, __FILE__, __LINE__,
+                             "the calling thread's grace context belongs to another device than the "
+                             "current one: hipSetDevice() to its device, or make a context of this "
+                             "device current (grace_context_set_current)");
+        *out = t_current;
+        return GRACE_OK;
+    }
+    if (dev < 0 || dev >= MAX_DEVICES)
+        return set_error(GRACE_INVALID_ARGUMENT, __FILE__, __LINE__, "device ordinal out of range");
+    Context* c = g_default_context[dev];
+    if (!c) {
+        std::lock_guard<std::mutex> lock(g_context_mutex);
+        c = g_default_context[dev];
+        if (!c) {
+            c = new Context();
+            c->device = dev;
+            g_default_context[dev] = c;
+        }
+    }
+    *out = c;
+    return GRACE_OK;
+}
+
+// Frees everything a context owns on its device (which must be current).
+static grace_status context_clear(Context& c)
+{
+    if (g_trace_state_destroy) GRACE_TRY(g_trace_state_destroy(c));
+    if (c.ws_base) {
+        GRACE_TRY_HIP(hipDeviceSynchronize());
+        GRACE_TRY_HIP(hipFree(c.ws_base));
+    }
+    c.ws_base = nullptr;
+    c.ws_capacity = c.ws_used = 0;
+    if (c.ws_fence) GRACE_TRY_HIP(hipEventDestroy(c.ws_fence));
+    c.ws_fence = nullptr;
+    c.ws_fence_valid = false;
+    c.ws_fence_stream = nullptr;
+    for (auto& e : c.phase_events) {
+        if (e) GRACE_TRY_HIP(hipEventDestroy(e));
+        e = nullptr;
+    }
+    c.phase_valid = false;
+    return GRACE_OK;
+}
+
+Context* Workspace::frame_context() { return t_frame; }
+
+grace_status Workspace::reserve(size_t bytes)
+{
+    Context* c = nullptr;
+    GRACE_TRY(current_context(&c));
+    if (bytes <= c->ws_capacity) return GRACE_OK;
     // Grow with headroom so that steady-state calls never allocate.
     size_t want = bytes + bytes / 4 + (size_t(1) << 20);
-    if (base_) {
+    if (c->ws_base) {
         GRACE_TRY_HIP(hipDeviceSynchronize());
-        GRACE_TRY_HIP(hipFree(base_));
-        base_ = nullptr;
-        capacity_ = 0;
+        GRACE_TRY_HIP(hipFree(c->ws_base));
+        c->ws_base = nullptr;
+        c->ws_capacity = 0;
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess)
         return set_error(GRACE_OUT_OF_MEMORY, __FILE__, __LINE__, hipGetErrorString(e));
-    base_ = static_cast<char*>(p);
-    capacity_ = want;
+    c->ws_base = static_cast<char*>(p);
+    c->ws_capacity = want;
     return GRACE_OK;
 }
 
 grace_status Workspace::begin(size_t bytes, hipStream_t stream)
 {
+    Context* c = nullptr;
+    GRACE_TRY(current_context(&c));
     GRACE_TRY(reserve(bytes));
-    // Frames alias: order this one behind the previous frame's stream when the stream changes.
-    static hipStream_t last_stream = nullptr;
-    static bool have_last = false;
-    static hipEvent_t fence = nullptr;
-    if (have_last && stream != last_stream) {
-        if (!fence) GRACE_TRY_HIP(hipEventCreateWithFlags(&fence, hipEventDisableTiming));
-        GRACE_TRY_HIP(hipEventRecord(fence, last_stream));
-        GRACE_TRY_HIP(hipStreamWaitEvent(stream, fence, 0));
-    }
-    last_stream = stream;
-    have_last = true;
-    used_ = 0;
+    // Frames alias: a frame on another stream than the previous one waits for the event that frame
+    // recorded on ITS stream when it closed (Workspace::end).  The previous stream's handle is only
+    // compared, never used: the caller may have destroyed it.
+    if (c->ws_fence_valid && stream != c->ws_fence_stream)
+        GRACE_TRY_HIP(hipStreamWaitEvent(stream, c->ws_fence, 0));
+    c->ws_used = 0;
+    c->ws_frame_open = true;
+    t_frame = c;
     return GRACE_OK;
+}
+
+void Workspace::end(hipStream_t stream)
+{
+    Context* c = t_frame;
+    if (!c || !c->ws_frame_open) return;
+    c->ws_frame_open = false;
+    if (!c->ws_fence && hipEventCreateWithFlags(&c->ws_fence, hipEventDisableTiming) != hipSuccess) {
+        c->ws_fence = nullptr;
+    }
+    if (c->ws_fence && hipEventRecord(c->ws_fence, stream) == hipSuccess) {
+        c->ws_fence_valid = true;
+        c->ws_fence_stream = stream;
+    } else {
+        // no fence: make the next frame safe the blunt way
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        c->ws_fence_valid = false;
+    }
 }
 
 grace_status Workspace::release()
 {
-    if (base_) {
+    Context* c = nullptr;
+    GRACE_TRY(current_context(&c));
+    if (c->ws_base) {
         GRACE_TRY_HIP(hipDeviceSynchronize());
-        GRACE_TRY_HIP(hipFree(base_));
+        GRACE_TRY_HIP(hipFree(c->ws_base));
     }
-    base_ = nullptr;
-    capacity_ = used_ = 0;
-    g_owner_device = -1;      // the next call may adopt another device
+    c->ws_base = nullptr;
+    c->ws_capacity = c->ws_used = 0;
+    c->ws_fence_valid = false;
     return GRACE_OK;
 }
 
@@ -147,5 +215,50 @@ grace_status grace_stream_synchronize(grace_stream s)
 grace_status grace_workspace_reserve(size_t bytes) { return Workspace::reserve(bytes); }
 
 grace_status grace_workspace_release(void) { return Workspace::release(); }
+
+grace_status grace_context_create(grace_context* ctx)
+{
+    GRACE_REQUIRE(ctx, "context_create: null output");
+    *ctx = nullptr;
+    int dev = -1;
+    GRACE_TRY_HIP(hipGetDevice(&dev));
+    Context* c = new Context();
+    c->device = dev;
+    *ctx = reinterpret_cast<grace_context>(c);
+    return GRACE_OK;
+}
+
+grace_status grace_context_destroy(grace_context ctx)
+{
+    if (!ctx) return GRACE_OK;
+    Context* c = reinterpret_cast<Context*>(ctx);
+    for (Context* d : g_default_context)
+        GRACE_REQUIRE(d != c, "context_destroy: a device's default context cannot be destroyed");
+    int dev = -1;
+    GRACE_TRY_HIP(hipGetDevice(&dev));
+    if (dev != c->device) GRACE_TRY_HIP(hipSetDevice(c->device));
+    grace_status st = context_clear(*c);
+    if (dev != c->device) GRACE_TRY_HIP(hipSetDevice(dev));
+    GRACE_TRY(st);
+    if (t_current == c) t_current = nullptr;
+    if (t_frame == c) t_frame = nullptr;
+    delete c;
+    return GRACE_OK;
+}
+
+grace_status grace_context_set_current(grace_context ctx)
+{
+    t_current = reinterpret_cast<Context*>(ctx);
+    return GRACE_OK;
+}
+
+grace_status grace_context_get_current(grace_context* ctx)
+{
+    GRACE_REQUIRE(ctx, "context_get_current: null output");
+    Context* c = nullptr;
+    GRACE_TRY(current_context(&c));
+    *ctx = reinterpret_cast<grace_context>(c);
+    return GRACE_OK;
+}
 
 } // extern "C"

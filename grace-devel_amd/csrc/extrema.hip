@@ -125,7 +125,8 @@ grace_status extrema_nc(const void* d_data, size_t n, size_t stride, void* h_min
 {
     int grid = stream_grid(n, EXT_BLOCK, 4);
     if (grid > EXT_MAX_BLOCKS) grid = EXT_MAX_BLOCKS;
-    GRACE_TRY(Workspace::begin(Workspace::aligned(size_t(grid) * 2 * NC * sizeof(T)) + 512, stream));
+    FrameGuard frame;
+    GRACE_TRY(frame.begin(Workspace::aligned(size_t(grid) * 2 * NC * sizeof(T)) + 512, stream));
     T* partial = Workspace::take<T>(size_t(grid) * 2 * NC);
     T* out = Workspace::take<T>(2 * NC);
     extrema_kernel<T, NC><<<grid, EXT_BLOCK, 0, stream>>>(static_cast<const char*>(d_data), n, stride,

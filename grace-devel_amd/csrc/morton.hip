@@ -118,7 +118,8 @@ grace_status minmax_f4(const float* d_v4, size_t n, float* h_mins4, float* h_max
                        hipStream_t stream)
 {
     GRACE_REQUIRE(d_v4 && n > 0, "minmax: empty input");
-    GRACE_TRY(Workspace::begin(256, stream));
+    FrameGuard frame;
+    GRACE_TRY(frame.begin(256, stream));
     uint32_t* d_out = Workspace::take<uint32_t>(8);
     GRACE_TRY_HIP(hipMemsetAsync(d_out, 0xFF, 16, stream));
     GRACE_TRY_HIP(hipMemsetAsync(d_out + 4, 0x00, 16, stream));
@@ -311,7 +312,8 @@ grace_status grace_centroid_bounds_tri(const float* d_tris, size_t n, float* h_b
 {
     GRACE_REQUIRE(d_tris && n > 0 && h_bot && h_top, "centroid_bounds_tri: bad argument");
     hipStream_t st = as_stream(stream);
-    GRACE_TRY(Workspace::begin(256, st));
+    FrameGuard frame;
+    GRACE_TRY(frame.begin(256, st));
     uint32_t* d_out = Workspace::take<uint32_t>(8);
     GRACE_TRY_HIP(hipMemsetAsync(d_out, 0xFF, 16, st));
     GRACE_TRY_HIP(hipMemsetAsync(d_out + 4, 0x00, 16, st));
@@ -393,7 +395,8 @@ grace_status grace_centroid_bounds_points(const void* d_points, size_t n, int is
     GRACE_REQUIRE(elems_per_point >= 3 && elems_per_point <= 16,
                   "centroid_bounds (points): elements per point must be 3..16");
     hipStream_t st = as_stream(stream);
-    GRACE_TRY(Workspace::begin(256, st));
+    FrameGuard frame;
+    GRACE_TRY(frame.begin(256, st));
     uint32_t* d_out = Workspace::take<uint32_t>(8);
     GRACE_TRY_HIP(hipMemsetAsync(d_out, 0xFF, 16, st));
     GRACE_TRY_HIP(hipMemsetAsync(d_out + 4, 0x00, 16, st));

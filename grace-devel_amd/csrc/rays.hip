@@ -348,7 +348,8 @@ static grace_status isotropic_rays(size_t n_rays, float ox, float oy, float oz, 
     GRACE_REQUIRE(n_rays > 0 && d_rays, "isotropic rays: bad argument");
     GRACE_TRY(rays_invalidate_if_written(d_rays));   // a prepared ray batch over this array is stale
     hipStream_t st = as_stream(stream);
-    GRACE_TRY(Workspace::begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28), st));
+    FrameGuard frame;
+    GRACE_TRY(frame.begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28), st));
     uint32_t* keys = Workspace::take<uint32_t>(n_rays);
     isotropic_kernel<<<stream_grid(n_rays, 256), 256, 0, st>>>(
         n_rays, ox, oy, oz, length, seed, octant, static_cast<float*>(d_rays), keys);
@@ -384,8 +385,9 @@ grace_status grace_rays_one_to_many(size_t n_rays, float ox, float oy, float oz,
     GRACE_REQUIRE(sort_type != 2 || (h_bot && h_top), "one_to_many_rays: end-point sort needs the points' bounds");
     hipStream_t st = as_stream(stream);
     uint32_t* keys = nullptr;
+    FrameGuard frame;
     if (sort_type != 0) {
-        GRACE_TRY(Workspace::begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28), st));
+        GRACE_TRY(frame.begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 28), st));
         keys = Workspace::take<uint32_t>(n_rays);
     }
     uint32_t* dir_keys = sort_type == 1 ? keys : nullptr;

@@ -389,7 +389,8 @@ grace_status segscan(const int* d_offsets, size_t n_seg, const T* d_data, size_t
     GRACE_REQUIRE(n_seg == 0 || d_offsets, "segmented scan: null offsets");
     if (n == 0) return GRACE_OK;
     const size_t n_slabs = (n + SCAN_SLAB - 1) / SCAN_SLAB;
-    GRACE_TRY(Workspace::begin(seg_ws_bytes<T>(n) + Workspace::aligned((n_slabs + 1) * 4), stream));
+    FrameGuard frame;
+    GRACE_TRY(frame.begin(seg_ws_bytes<T>(n) + Workspace::aligned((n_slabs + 1) * 4), stream));
     uint32_t* table = Workspace::take<uint32_t>(n_slabs + 1);
     seg_slab_bounds_kernel<<<int((n_slabs + 256) / 256), 256, 0, stream>>>(d_offsets, n_seg, n_slabs,
                                                                             table);
@@ -465,7 +466,8 @@ grace_status grace_scan_exclusive_i32(const int* d_in, size_t n, int* d_out, lon
 {
     GRACE_REQUIRE(n == 0 || (d_in && d_out), "scan: null pointer");
     hipStream_t st = as_stream(stream);
-    GRACE_TRY(Workspace::begin((scan_ws_count(n) + 128) * sizeof(uint32_t), st));
+    FrameGuard frame;
+    GRACE_TRY(frame.begin((scan_ws_count(n) + 128) * sizeof(uint32_t), st));
     unsigned long long* d_total = Workspace::take<unsigned long long>(1);
     uint32_t* scratch = Workspace::take<uint32_t>(scan_ws_count(n));
     if (h_total) {

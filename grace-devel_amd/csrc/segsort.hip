@@ -190,10 +190,11 @@ grace_status grace_sort_by_distance_f32(float* d_distances, const int* d_ray_off
     GRACE_REQUIRE(n_hits < (size_t(1) << 32), "sort_by_distance: at most 2^32 - 1 hits");
     if (n_hits < 2 || n_rays == 0) return GRACE_OK;
     hipStream_t st = as_stream(stream);
+    FrameGuard frame;
     // Typical ray segments (up to tens of thousands of hits): one wavefront per segment.
     // Very long segments on average: the composite-key global sort below.
     if (n_hits / n_rays <= 32768) {
-        GRACE_TRY(Workspace::begin(7 * Workspace::aligned(n_hits * 4) + 1024, st));
+        GRACE_TRY(frame.begin(7 * Workspace::aligned(n_hits * 4) + 1024, st));
         uint32_t* k0 = Workspace::take<uint32_t>(n_hits);
         uint32_t* k1 = Workspace::take<uint32_t>(n_hits);
         uint32_t* i0 = Workspace::take<uint32_t>(n_hits);
@@ -210,7 +211,7 @@ grace_status grace_sort_by_distance_f32(float* d_distances, const int* d_ray_off
     const size_t ws = 3 * Workspace::aligned(n_hits * 4) + Workspace::aligned(scan_ws_count(n_hits) * 4)
         + Workspace::aligned(n_hits * 8) + Workspace::aligned(n_hits * 4)
         + sort_ws_bytes(n_hits, 8, 0) + 1024;
-    GRACE_TRY(Workspace::begin(ws, st));
+    GRACE_TRY(frame.begin(ws, st));
     uint32_t* heads = Workspace::take<uint32_t>(n_hits);
     uint32_t* heads_excl = Workspace::take<uint32_t>(n_hits);
     uint32_t* perm = Workspace::take<uint32_t>(n_hits);
@@ -257,7 +258,8 @@ grace_status grace_sort_by_distance_f64(double* d_distances, const int* d_ray_of
     GRACE_REQUIRE(n_hits < (size_t(1) << 32), "sort_by_distance: at most 2^32 - 1 hits");
     if (n_hits < 2 || n_rays == 0) return GRACE_OK;
     hipStream_t st = as_stream(stream);
-    GRACE_TRY(Workspace::begin(4 * Workspace::aligned(n_hits * 8) + 3 * Workspace::aligned(n_hits * 4) + 1024, st));
+    FrameGuard frame;
+    GRACE_TRY(frame.begin(4 * Workspace::aligned(n_hits * 8) + 3 * Workspace::aligned(n_hits * 4) + 1024, st));
     uint64_t* k0 = Workspace::take<uint64_t>(n_hits);
     uint64_t* k1 = Workspace::take<uint64_t>(n_hits);
     uint32_t* i0 = Workspace::take<uint32_t>(n_hits);

@@ -225,8 +225,9 @@ grace_status sort_pairs(Key* d_keys, void* d_values, size_t n, int value_bytes, 
     }
     const uint32_t n_tiles = uint32_t((n + SORT_TILE - 1) / SORT_TILE);
     const size_t n_counts = size_t(RADIX) * n_tiles;
+    FrameGuard frame;
     if (!nested)
-        GRACE_TRY(Workspace::begin(sort_ws_bytes_impl(n, sizeof(Key), d_values ? value_bytes : 0), stream));
+        GRACE_TRY(frame.begin(sort_ws_bytes_impl(n, sizeof(Key), d_values ? value_bytes : 0), stream));
     Key* keys_alt = Workspace::take<Key>(n);
     uint32_t* idx_a = Workspace::take<uint32_t>(n);
     uint32_t* idx_b = Workspace::take<uint32_t>(n);

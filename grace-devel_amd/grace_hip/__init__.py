@@ -319,6 +319,45 @@ def set_exact_integrals(enabled):
     _check(_lib.grace_trace_set_exact_integrals(C.c_int(1 if enabled else 0)))
 
 
+def set_lattice_split(k):
+    _check(_lib.grace_trace_set_lattice_split(C.c_int(k)))
+
+
+def set_hits_staging(enabled):
+    _check(_lib.grace_trace_set_hits_staging(C.c_int(1 if enabled else 0)))
+
+
+class Context:
+    """A library context (include/grace_hip.h, "contexts"): workspace, cached scene / ray order,
+    knobs and status word of its own, on the device that is current at creation.  Use as
+    `with Context(): ...` in the thread that should run on it."""
+
+    def __init__(self):
+        self._h = C.c_void_p(0)
+        _check(_lib.grace_context_create(C.byref(self._h)))
+
+    def make_current(self):
+        _check(_lib.grace_context_set_current(self._h))
+
+    @staticmethod
+    def reset_current():
+        _check(_lib.grace_context_set_current(C.c_void_p(0)))
+
+    def destroy(self):
+        if self._h:
+            _check(_lib.grace_context_destroy(self._h))
+            self._h = C.c_void_p(0)
+
+    def __enter__(self):
+        self.make_current()
+        return self
+
+    def __exit__(self, *exc):
+        Context.reset_current()
+        self.destroy()
+        return False
+
+
 def set_treelet_size(n):
     _check(_lib.grace_trace_set_treelet_size(C.c_int(int(n))))
 

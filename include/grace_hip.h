@@ -17,13 +17,15 @@
  *    of the calling thread.
  *  - Temporaries come from a grow-only device workspace owned by the library (the
  *    reference allocates and frees thrust temporaries inside every call).  Workspace, status
- *    word, prepared trace scene, timing events and tuning knobs are PROCESS-GLOBAL: one device
- *    and one stream at a time per process, no concurrent calls from several host threads --
- *    exactly the reference's constraints (global texture references, default stream:
- *    include/grace/cuda/kernels/bintree_trace.cuh:37-38) and the shape of one process per GPU.
- *    A call made with a different device current than the workspace's is refused with
- *    GRACE_INVALID_ARGUMENT (grace_workspace_release() lets the next call adopt another
- *    device); the single-process ncclCommInitAll form of multi-GPU use is not supported.
+ *    word, cached trace scene / ray order, timing events and tuning knobs belong to a CONTEXT.
+ *    Every device has a default context, used by threads that never ask for another: with one
+ *    process per GPU, or one process that sets a device current and calls, nothing needs to be
+ *    done.  A context serves one call at a time; host threads may call concurrently iff each has
+ *    made a context of its own current (grace_context_create / grace_context_set_current) -- one
+ *    thread per GPU of a node, or several threads sharing one GPU.  Calls may use any stream;
+ *    consecutive calls of a context on different streams are ordered by the library (their
+ *    temporaries share memory), and a stream may be destroyed as soon as the caller has
+ *    synchronised with it.
  *  - float4 / int4 / Ray arrays are passed as float* / int* / void* with the reference's
  *    memory layout: sphere = {x, y, z, h}; Ray = {dx,dy,dz,ox,oy,oz,length} (28 B,
  *    include/grace/ray.h:5-10); node = 4 x 16 B, leaf = int4 (include/grace/cuda/nodes.h:22-42).
@@ -60,9 +62,24 @@ grace_status grace_memcpy_dtoh(void* h_dst, const void* d_src, size_t bytes, gra
 grace_status grace_memcpy_dtod(void* d_dst, const void* d_src, size_t bytes, grace_stream stream);
 grace_status grace_memset(void* d_dst, int byte, size_t bytes, grace_stream stream);
 grace_status grace_stream_synchronize(grace_stream stream);
-/* Pre-size / drop the internal workspace (optional). */
+/* Pre-size / drop the workspace of the calling thread's context (optional). */
 grace_status grace_workspace_reserve(size_t bytes);
 grace_status grace_workspace_release(void);
+
+/* ---- contexts: everything the library keeps between calls (see Conventions).  The reference has
+ *      one set of globals per process (texture references, bintree_trace.cuh:37-38) and drives
+ *      several GPUs from one process only through ncclCommInitAll-style code of the caller's
+ *      (SURVEY.md section 8e); a context per (thread, device) is what makes that form work here.
+ *      grace_context_create: a fresh context on the CURRENT device.  grace_context_set_current:
+ *      the calling thread's context from now on (NULL: back to the current device's default
+ *      context).  grace_context_destroy frees the context's device memory and events (its device
+ *      is made current for the duration); default contexts are never destroyed.
+ *      grace_context_get_current returns the context the next call of this thread would use. */
+typedef struct grace_context_s* grace_context;
+grace_status grace_context_create(grace_context* ctx);
+grace_status grace_context_destroy(grace_context ctx);
+grace_status grace_context_set_current(grace_context ctx);
+grace_status grace_context_get_current(grace_context* ctx);
 
 /* ---- Morton keys ------------------------------------------------------------------- */
 /* AABB of sphere centroids: compute_centroids + min_vec3/max_vec3
@@ -300,6 +317,14 @@ grace_status grace_trace_set_exact_integrals(int enabled);
  * (results per ray unchanged).  0 disables; -1 (default) = 16384 for axis-aligned packets (whose
  * cluster test is a sharp box-rectangle overlap), 512 for the others. */
 grace_status grace_trace_set_treelet_size(int max_primitives);
+
+/* Measurement switches (results never depend on them).  Lattice split: waves per packet that a
+ * batch of >= 16384 packets gets when the device finds spheres smaller than the ray spacing in the
+ * scene (clustered SPH data): 0 = one wave per packet, 2, 4 (default) or 8.  Hits staging: 0 = the
+ * split per-hit walk of small batches always stores hits directly (default 1: heavy packets stage
+ * them in LDS). */
+grace_status grace_trace_set_lattice_split(int waves_per_packet);
+grace_status grace_trace_set_hits_staging(int enabled);
 
 /* Scene-constant trace data.  Every trace call derives, from the primitives and the tree alone,
  * per-sphere records ({x, y, z, h^2}, {1/h, 1/h^2}), every node's primitive span and one box per

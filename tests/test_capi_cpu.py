@@ -72,6 +72,20 @@ def test_reference_header_paths_compile_with_hipcc(tmp_path):
         assert exe.exists()
 
 
+def test_single_process_sharded_program_compiles_against_rccl(tmp_path):
+    """tests/cpp/project_gadget_sharded.hip: one process, one thread + one library context per
+    rank, ncclCommInitAll + ncclAllGather of 4 B/ray -- compiles against
+    /opt/rocm/include/rccl/rccl.h and links librccl (run on the GPU by tests/test_gpu_round3.py)."""
+    exe = tmp_path / "project_gadget_sharded"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17",
+                           "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "tests", "cpp"),
+                           os.path.join(ROOT, "tests", "cpp", "project_gadget_sharded.hip"), "-o", str(exe),
+                           "-L" + os.path.dirname(LIB), "-lgrace_hip", "-L/opt/rocm/lib", "-lrccl", "-pthread",
+                           "-Wl,-rpath," + os.path.dirname(LIB)])
+    assert exe.exists()
+
+
 def test_host_morton_key_known_answers(tmp_path, oracle):
     """BASELINE config 1 (tests/morton_key: the CPU host path) on the PRODUCT headers
     include/grace/generic/{bits,morton}.h, built with plain g++: the reference's own known-answer

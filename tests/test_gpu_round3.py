@@ -1,11 +1,19 @@
 """Round-3 GPU tests: the generic build entry (caller-evaluated boxes, thrust::greater), the
 generic extrema, weighted scan in double -- all through the C ABI (ctypes), against the oracle /
 numpy."""
+import ctypes as C
+import math
+import os
+import subprocess
+import threading
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "grace-devel_amd", "lib")
 
 
 def _dev(a, cuda):
@@ -93,3 +101,137 @@ def test_weighted_segmented_scan_double(gh, cuda):
     for b, e in zip(offs, ends):
         c = np.cumsum(wx[b:e]); ref[b:e] = c - wx[b:e]
     assert np.array_equal(out.cpu().numpy(), ref)
+
+
+# ---- contexts, streams ---------------------------------------------------------------------------
+def _projection_scene(gh, oracle, cuda, n=150000, side=256, mpl=32):
+    s = oracle.random_real4(n, (0, 0, 0, 0.004), (1, 1, 1, 0.02))
+    d = _dev(s, cuda)
+    lo, hi = gh.min_max_vec4(d)
+    lo[3] = hi[3] = 0.0
+    tree = gh.Tree(n, mpl, device=cuda)
+    gh.build_tree(d, tree, lo[:3], hi[:3])
+    rays, _ = gh.orthogonal_rays_z(side, lo, hi, device=cuda)
+    return d, tree, rays
+
+
+def test_trace_after_the_previous_stream_was_destroyed(gh, oracle, cuda):
+    """A C-ABI caller may destroy a stream between calls (the workspace fence used to be
+    recorded on the PREVIOUS call's stream handle).  Trace on stream A, destroy A, trace on stream
+    B, then on the default stream: same bits every time."""
+    hip = C.CDLL("libamdhip64.so")
+    d, tree, rays = _projection_scene(gh, oracle, cuda)
+    ref = torch.empty(len(rays), dtype=torch.float32, device=cuda)
+    gh.trace_cumulative_sph(rays, d, tree, ref)
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        h = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(h)) == 0
+        ext = torch.cuda.ExternalStream(h.value)
+        out = torch.empty_like(ref)
+        with torch.cuda.stream(ext):
+            gh.trace_cumulative_sph(rays, d, tree, out)
+            counts = torch.empty(len(rays), dtype=torch.int32, device=cuda)
+            gh.trace_hitcounts_sph(rays, d, tree, counts)
+        assert hip.hipStreamSynchronize(h) == 0
+        assert hip.hipStreamDestroy(h) == 0
+        outs.append(out)
+    out = torch.empty_like(ref)
+    gh.trace_cumulative_sph(rays, d, tree, out)      # default stream, after the last destroy
+    gh.trace_status()
+    torch.cuda.synchronize()
+    for o in outs + [out]:
+        assert torch.equal(o, ref)
+
+
+def test_two_contexts_on_one_gpu_from_two_threads(gh, oracle, cuda):
+    """Library state is per context: two host threads, each with a context and
+    a stream of its own, trace different shards of one frame concurrently, several times over --
+    every result equals the single-context image bit for bit; knobs set in one context do not
+    leak into the other."""
+    d, tree, rays = _projection_scene(gh, oracle, cuda, n=200000, side=256)
+    ref = torch.empty(len(rays), dtype=torch.float32, device=cuda)
+    gh.trace_cumulative_sph(rays, d, tree, ref)
+    gh.set_exact_integrals(True)
+    ref_exact = torch.empty_like(ref)
+    gh.trace_cumulative_sph(rays, d, tree, ref_exact)
+    gh.set_exact_integrals(False)
+    torch.cuda.synchronize()
+    assert not torch.equal(ref, ref_exact)
+    half = len(rays) // 2
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(cuda)
+            with gh.Context():
+                gh.set_exact_integrals(k == 1)        # this context only
+                want = (ref_exact if k == 1 else ref)[k * half:(k + 1) * half]
+                mine = rays[k * half:(k + 1) * half]
+                stream = torch.cuda.Stream(device=cuda)
+                with torch.cuda.stream(stream):
+                    for it in range(6):
+                        out = torch.empty(half, dtype=torch.float32, device=cuda)
+                        gh.trace_cumulative_sph(mine, d, tree, out)
+                        if it % 2:
+                            cnt = torch.empty(half, dtype=torch.int32, device=cuda)
+                            gh.trace_hitcounts_sph(mine, d, tree, cnt)
+                        stream.synchronize()
+                        if not torch.equal(out, want):
+                            errors.append((k, it, "differs"))
+                    gh.trace_status()
+        except Exception as e:      # noqa: BLE001 -- reported to the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    # the default context still has its own (default) knobs
+    again = torch.empty_like(ref)
+    gh.trace_cumulative_sph(rays, d, tree, again)
+    assert torch.equal(again, ref)
+
+
+def _build_sharded(tmp_path):
+    exe = str(tmp_path / "project_gadget_sharded")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17",
+                           "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "tests", "cpp"),
+                           os.path.join(ROOT, "tests", "cpp", "project_gadget_sharded.hip"), "-o", exe,
+                           "-L" + LIBDIR, "-lgrace_hip", "-L/opt/rocm/lib", "-lrccl", "-pthread",
+                           "-Wl,-rpath," + LIBDIR])
+    return exe
+
+
+def test_single_process_sharded_projection(tmp_path, gh, cuda):
+    """One process, one thread + one library context per rank (tests/cpp/project_gadget_sharded.hip):
+    with one rank the gather is a real ncclAllGather (RCCL, communicator from ncclCommInitAll); with
+    three ranks sharing the one GPU of the test box the three contexts trace concurrently and the
+    gather is device-to-device copies (RCCL refuses two ranks per device).  Either way the gathered
+    image equals the unsharded one, and the ctypes path's, bit for bit."""
+    from grace_hip import gadget
+    n, side = 120000, 160
+    rng = np.random.default_rng(21)
+    pos = rng.random((n, 3), dtype=np.float32)
+    h = np.full(n, (3 * 48 / (4 * math.pi * n)) ** (1 / 3), np.float32) * (0.8 + 0.4 * rng.random(n, dtype=np.float32))
+    snap = str(tmp_path / "snap")
+    gadget.write_gadget(snap, pos, h)
+    exe = _build_sharded(tmp_path)
+    s = torch.from_numpy(gadget.read_gadget(snap)).to(cuda)
+    lo, hi = gh.min_max_vec4(s)
+    lo[3] = hi[3] = 0.0
+    tree = gh.Tree(n, 32, device=cuda)
+    gh.build_tree(s, tree, lo[:3], hi[:3])
+    rays, _ = gh.orthogonal_rays_z(side, lo, hi, device=cuda)
+    img = torch.empty(len(rays), dtype=torch.float32, device=cuda)
+    gh.trace_cumulative_sph(rays, s, tree, img)
+    for extra in (["1"], ["3", "share"]):
+        out = str(tmp_path / ("img_%s.f32" % extra[0]))
+        r = subprocess.run([exe, str(side * side // 32), "32", snap, out] + extra, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
+        assert np.array_equal(np.fromfile(out, np.float32).view(np.uint32), img.cpu().numpy().view(np.uint32))
