@@ -8,9 +8,15 @@ semantics) on the project_gadget workload -- 10^7 particles, ONE 1024^2 orthogra
 One process per GPU (torch.distributed / RCCL when N > 1): every rank builds the same BVH
 from the same seeded particles (the tree is replicated), traces its own contiguous shard of
 the job's ray batch, and the per-ray integrals are all-gathered over RCCL (the only
-collective; 4 B/ray).  A "step" = one trace of the whole ray batch (+ the gather when N > 1)
-with particles, tree, the scene's pre-pass records (grace_trace_prepare_f4: scene-constant,
-computed once after the build like the tree itself) and rays resident in HBM.
+collective; 4 B/ray).  A "step" = one STATELESS call trace_cumulative_sph(rays, spheres, tree, out)
+of the whole ray batch -- the call a drop-in user of the reference makes -- (+ the gather when
+N > 1), with particles, tree and rays resident in HBM.  The library caches what a call derives
+from its inputs alone (pre-pass records, ray coherence order) once it has seen the same arrays
+twice, and validates the cache against the arrays' current contents on every call (a signature
+pass on the device); the steady state the timed loop measures therefore includes that validation.
+Also reported: `cold_call_ms` (caching off: every call re-derives everything) and
+`value_trusted` (validation off: the caller promises not to modify the arrays -- round 2's
+"prepared" number).
 
   --scaling strong (default): the job is the single 1024^2 frame of configs[3], cut into N
       contiguous ray shards -- BASELINE.json's "rays sharded over 8xMI355X".
@@ -23,7 +29,7 @@ N = 1) as the thing timed on the host cores, never in the GPU path.
 roofline: the traversal is NOT HBM-bound (its working set is cache-resident; measured HBM
 traffic is a few % of peak) -- its ceiling is VALU issue.  `achieved` / `peak` are vector
 wave-instructions per second: the kernel's SQ_INSTS_VALU per launch (rocprofv3 PMC pass
-committed under profiles/, keyed by the sha256 of csrc/trace.hip it was collected on; null
+committed under profiles/, keyed by the sha256 of csrc/trace_kernel.hpp it was collected on; null
 when that no longer matches) over the kernel duration measured live in THIS run with HIP
 events, against 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 fp32 instruction.
 """
@@ -47,8 +53,8 @@ N_SIMDS = 256 * 4
 MAX_CLOCK_GHZ = 2.4
 VALU_PEAK_GINST = N_SIMDS * MAX_CLOCK_GHZ / 2.0   # v_fma_f32 wave64: 2 cycles per SIMD-32
 MIN_VALU_PER_HIT = 12   # sub sub mul fma | sqrt mul min cvt fract shl | fma fma (csrc/trace.hip, lean fast round)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_trace.json")
-TRACE_SRC = os.path.join(ROOT, "grace-devel_amd", "csrc", "trace.hip")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_trace.json")
+TRACE_SRC = os.path.join(ROOT, "grace-devel_amd", "csrc", "trace_kernel.hpp")   # the kernel's source
 
 
 def make_particles(n, device, seed=42):
@@ -153,13 +159,13 @@ def load_pmc(kernel_name):
     except Exception as e:
         return None, "no PMC file (%s)" % e
     sha = hashlib.sha256(open(TRACE_SRC, "rb").read()).hexdigest()
-    if pmc.get("trace_hip_sha256") != sha:
-        return None, "stale: profiles/r02_pmc_trace.json was collected on trace.hip %s, this is %s" % (
-            str(pmc.get("trace_hip_sha256"))[:12], sha[:12])
+    if pmc.get("trace_kernel_sha256") != sha:
+        return None, "stale: %s was collected on trace_kernel.hpp %s, this is %s" % (
+            os.path.relpath(PMC_FILE, ROOT), str(pmc.get("trace_kernel_sha256"))[:12], sha[:12])
     k = pmc.get("kernels", {}).get(kernel_name)
     if not k:
         return None, "kernel %s not in the PMC file" % kernel_name
-    return dict(k, source=os.path.relpath(PMC_FILE, ROOT), trace_hip_sha256=sha[:16],
+    return dict(k, source=os.path.relpath(PMC_FILE, ROOT), trace_kernel_sha256=sha[:16],
                 collected_at_commit=pmc.get("collected_at_commit")), None
 
 
@@ -170,14 +176,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--particles", type=int, default=10_000_000)
     ap.add_argument("--side", type=int, default=1024)
-    ap.add_argument("--no-prepare-rays", action="store_true",
-                    help="recompute the ray coherence order (extents, keys, partial sort) in every "
-                         "trace call instead of once before the loop (grace_trace_prepare_rays)")
+    ap.add_argument("--no-cache", action="store_true",
+                    help="grace_trace_set_cache_auto(0): every call re-derives pre-pass records and "
+                         "ray order (the cold call) -- the timed loop then measures that")
     ap.add_argument("--max-per-leaf", type=int, default=32)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prepare", action="store_true",
-                    help="recompute the scene's pre-pass records inside every trace call")
+    ap.add_argument("--trusted", action="store_true",
+                    help="grace_trace_set_cache_validation(0) + grace_trace_prepare_*: cached records "
+                         "are used on the caller's promise, no signature pass (round 2's prepared call)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -286,27 +293,31 @@ def main():
         gh.trace_cumulative_sph(my_rays, spheres, tree, buf[: r1 - r0])
         return pipe.gather(k)
 
-    # The same step without the prepared scene (every call then recomputes the per-sphere
-    # records, node spans and cluster boxes), for the record.
-    unprepared_ms = None
-    if not args.no_prepare:
-        trace_once(); torch.cuda.synchronize()
+    def timed_calls(reps):
+        trace_once(); trace_once(); trace_once(); torch.cuda.synchronize()    # reach the steady state
         t1 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(reps):
             trace_once()
         torch.cuda.synchronize()
-        unprepared_ms = 1e3 * (time.perf_counter() - t1) / 5
+        return 1e3 * (time.perf_counter() - t1) / reps
+
+    # For the record (never `value`): the cold call -- caching off, every call derives the
+    # per-sphere records, node spans, cluster boxes and the ray coherence order afresh -- and the
+    # trusted call -- caches pinned, validation off (the caller's promise; round 2's headline).
+    gh.set_cache_auto(False)
+    cold_ms = timed_calls(5)
+    gh.set_cache_auto(True)
+    gh.set_cache_validation(False)
+    gh.trace_prepare(spheres, tree)
+    gh.trace_prepare_rays(my_rays)
+    trusted_ms = timed_calls(20)
+    gh.trace_release(); gh.trace_release_rays()
+    gh.set_cache_validation(True)
+    if args.no_cache:
+        gh.set_cache_auto(False)
+    if args.trusted:
+        gh.set_cache_validation(False)
         gh.trace_prepare(spheres, tree)
-    # ... and without the prepared ray batch (every call then recomputes the ray coherence order:
-    # extents, keys, partial sort -- the reference's generators sort rays once, at generation).
-    unordered_ms = None
-    if not args.no_prepare_rays:
-        trace_once(); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            trace_once()
-        torch.cuda.synchronize()
-        unordered_ms = 1e3 * (time.perf_counter() - t1) / 5
         gh.trace_prepare_rays(my_rays)
 
     for _ in range(args.warmup):
@@ -329,8 +340,8 @@ def main():
 
     # ---- kernel and call durations: HIP events, after the timed region ----------------------
     # In-library events sit directly around the traversal kernel on its stream
-    # (grace_trace_enable_timing); torch events around the whole call add the per-call ray
-    # coherence pass (extents, keys, partial sort).
+    # (grace_trace_enable_timing); torch events around the whole call add the signature pass that
+    # validates the cached records (or, cold, the pre-pass and the ray coherence pass).
     gh.enable_kernel_timing(True)
     k_rep = max(3, min(args.steps, 20))
     trace_ms, call_ev = [], []
@@ -431,8 +442,10 @@ def main():
                                                         args.max_per_leaf),
                        "particles": n, "rays": n_rays, "frames": frames,
                        "max_per_leaf": args.max_per_leaf,
-                       "scene_prepared": not args.no_prepare,
-                       "rays_prepared": not args.no_prepare_rays,
+                       "call": ("trusted (validation off, caches pinned)" if args.trusted else
+                                "cold (caching off)" if args.no_cache else
+                                "stateless trace_cumulative_sph(rays, spheres, tree, out); the library's "
+                                "validated cache of pre-pass records and ray order is in its steady state"),
                        "sharding": "%d frame(s) of %d rays, contiguous ray shards over %d "
                                    "rank(s), BVH replicated, all_gather of 4 B/ray (two output "
                                    "buffers: step k's gather overlaps step k+1's trace)"
@@ -441,8 +454,13 @@ def main():
             "build": dict(phases, n_leaves=tree.n_leaves,
                           total_ms=round(sum(phases.values()), 4)),
             "image": {"mean": float(img.mean()), "max": float(img.max())},
-            "unprepared_ms_per_call": None if unprepared_ms is None else round(unprepared_ms, 4),
-            "ray_order_per_call_ms_per_call": None if unordered_ms is None else round(unordered_ms, 4),
+            # every record re-derived per call (grace_trace_set_cache_auto(0)): what the FIRST call
+            # on a scene / ray batch costs
+            "cold_call_ms": round(cold_ms, 4), "cold_Mrays/s": round(n_rays / world / cold_ms / 1e3, 2),
+            # caches pinned, signature validation off (grace_trace_set_cache_validation(0)): the
+            # caller's promise instead of the library's check -- round 2's headline configuration
+            "trusted_call_ms": round(trusted_ms, 4),
+            "value_trusted": round(n_rays / world / trusted_ms / 1e3, 2),
             "bit_exact_integrals": None if exact_ms is None else
                 {"ms_per_step": round(exact_ms, 4), "Mrays/s": round(n_rays / exact_ms / 1e3, 2)},
         }

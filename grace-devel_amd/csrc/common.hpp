@@ -138,15 +138,17 @@ inline int stream_grid(size_t n, int block, int items_per_thread = 1)
 // Exclusive prefix sum of n uint32 (in place allowed).  d_total (optional, device) gets
 // the grand total.  Needs scan_ws_count(n) uint32 of scratch.
 size_t scan_ws_count(size_t n);
+// run_if (device, optional): every kernel returns at once if *run_if == 0.
 grace_status exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, size_t n,
-                                uint32_t* d_scratch, uint32_t* d_total, hipStream_t stream);
+                                uint32_t* d_scratch, uint32_t* d_total, hipStream_t stream,
+                                const uint32_t* run_if = nullptr);
 
 // Stable radix sort used inside other entry points.  The caller has already opened a
 // workspace frame that includes sort_ws_bytes(); temporaries are carved from it.
 size_t sort_ws_bytes(size_t n, int key_bytes, int value_bytes);
 grace_status sort_pairs_u32_nested(uint32_t* d_keys, void* d_values, size_t n, int value_bytes,
                                    int begin_bit, int end_bit, uint32_t* d_perm,
-                                   hipStream_t stream);
+                                   hipStream_t stream, const uint32_t* run_if = nullptr);
 grace_status sort_pairs_u64_nested(uint64_t* d_keys, void* d_values, size_t n, int value_bytes,
                                    int begin_bit, int end_bit, uint32_t* d_perm,
                                    hipStream_t stream);

@@ -53,8 +53,10 @@ __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* s_
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(const uint32_t* __restrict__ in,
                                                                  size_t n,
-                                                                 uint32_t* __restrict__ sums)
+                                                                 uint32_t* __restrict__ sums,
+                                                                 const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     const size_t slab0 = size_t(blockIdx.x) * SCAN_SLAB;
     uint32_t acc = 0;
 #pragma unroll
@@ -77,8 +79,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(const uint32_t*
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_slab_kernel(const uint32_t* in, uint32_t* out,
                                                                size_t n,
                                                                const uint32_t* __restrict__ carry_in,
-                                                               uint32_t* __restrict__ total_out)
+                                                               uint32_t* __restrict__ total_out,
+                                                               const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t s_wave[SCAN_BLOCK / 64];
     const size_t slab0 = size_t(blockIdx.x) * SCAN_SLAB;
     uint32_t carry = carry_in ? carry_in[blockIdx.x] : 0u;
@@ -111,6 +115,38 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_slab_kernel(const uint32_t* i
     if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = carry;
 }
 
+// Small inputs (the radix sort's digit tables of up to 2^18 counters -- the ray-order sort's 65536
+// -- and the like): ONE workgroup of 1024 threads, each thread owning a contiguous run, instead of
+// reduce / scan-of-sums / scan launches of a few microseconds each.
+constexpr int SCAN_SMALL_BLOCK = 1024;
+constexpr size_t SCAN_SMALL_MAX = size_t(1) << 18;
+
+__global__ __launch_bounds__(SCAN_SMALL_BLOCK) void scan_small_kernel(const uint32_t* in, uint32_t* out,
+                                                                      size_t n,
+                                                                      uint32_t* __restrict__ total_out,
+                                                                      const uint32_t* __restrict__ run_if)
+{
+    if (run_if && *run_if == 0u) return;
+    __shared__ uint32_t s_wave[SCAN_SMALL_BLOCK / 64];
+    const size_t per = (n + SCAN_SMALL_BLOCK - 1) / SCAN_SMALL_BLOCK;
+    const size_t lo = min(size_t(threadIdx.x) * per, n), hi = min(lo + per, n);
+    uint32_t sum = 0;
+    for (size_t i = lo; i < hi; ++i) sum += in[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_inclusive_sum(sum, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int w = 0; w < SCAN_SMALL_BLOCK / 64; ++w) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    uint32_t run = base + incl - sum;
+    for (size_t i = lo; i < hi; ++i) { const uint32_t v = in[i]; out[i] = run; run += v; }
+    if (total_out && threadIdx.x == 0) *total_out = tot;
+}
+
 } // namespace
 
 namespace grace_hip {
@@ -126,26 +162,32 @@ size_t scan_ws_count(size_t n)
 }
 
 grace_status exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, size_t n,
-                                uint32_t* d_scratch, uint32_t* d_total, hipStream_t stream)
+                                uint32_t* d_scratch, uint32_t* d_total, hipStream_t stream,
+                                const uint32_t* run_if)
 {
     if (n == 0) {
         if (d_total) GRACE_TRY_HIP(hipMemsetAsync(d_total, 0, 4, stream));
         return GRACE_OK;
     }
     const size_t n_slabs = (n + SCAN_SLAB - 1) / SCAN_SLAB;
+    if (n_slabs > 1 && n <= SCAN_SMALL_MAX) {
+        scan_small_kernel<<<1, SCAN_SMALL_BLOCK, 0, stream>>>(d_in, d_out, n, d_total, run_if);
+        GRACE_CHECK_LAUNCH();
+        return GRACE_OK;
+    }
     if (n_slabs == 1) {
-        scan_slab_kernel<<<1, SCAN_BLOCK, 0, stream>>>(d_in, d_out, n, nullptr, d_total);
+        scan_slab_kernel<<<1, SCAN_BLOCK, 0, stream>>>(d_in, d_out, n, nullptr, d_total, run_if);
         GRACE_CHECK_LAUNCH();
         return GRACE_OK;
     }
     uint32_t* sums = d_scratch;
     uint32_t* next_scratch = d_scratch + ((n_slabs + 63) & ~size_t(63));
-    scan_reduce_kernel<<<int(n_slabs), SCAN_BLOCK, 0, stream>>>(d_in, n, sums);
+    scan_reduce_kernel<<<int(n_slabs), SCAN_BLOCK, 0, stream>>>(d_in, n, sums, run_if);
     GRACE_CHECK_LAUNCH();
     // The carry of slab b is the exclusive prefix of the slab sums; the last slab's
     // running carry is the grand total, so the recursion does not need to report one.
-    GRACE_TRY(exclusive_scan_u32(sums, sums, n_slabs, next_scratch, nullptr, stream));
-    scan_slab_kernel<<<int(n_slabs), SCAN_BLOCK, 0, stream>>>(d_in, d_out, n, sums, d_total);
+    GRACE_TRY(exclusive_scan_u32(sums, sums, n_slabs, next_scratch, nullptr, stream, run_if));
+    scan_slab_kernel<<<int(n_slabs), SCAN_BLOCK, 0, stream>>>(d_in, d_out, n, sums, d_total, run_if);
     GRACE_CHECK_LAUNCH();
     return GRACE_OK;
 }

@@ -41,8 +41,10 @@ template <typename Key>
 __global__ __launch_bounds__(SORT_BLOCK) void sort_hist_kernel(const Key* __restrict__ keys,
                                                                size_t n, int shift, uint32_t mask,
                                                                uint32_t n_tiles,
-                                                               uint32_t* __restrict__ counts)
+                                                               uint32_t* __restrict__ counts,
+                                                               const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t s_hist[RADIX];
     s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -61,8 +63,10 @@ template <typename Key, bool FIRST>
 __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
     const Key* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
     Key* __restrict__ keys_out, uint32_t* __restrict__ idx_out, size_t n, int shift,
-    uint32_t mask, uint32_t n_tiles, const uint32_t* __restrict__ bases)
+    uint32_t mask, uint32_t n_tiles, const uint32_t* __restrict__ bases,
+    const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     __shared__ uint32_t s_cnt[SORT_WAVES][RADIX];
     for (int k = threadIdx.x; k < SORT_WAVES * RADIX; k += SORT_BLOCK) (&s_cnt[0][0])[k] = 0;
     __syncthreads();
@@ -210,15 +214,21 @@ size_t sort_ws_bytes_impl(size_t n, int key_bytes, int value_bytes)
 
 template <typename Key>
 grace_status sort_pairs(Key* d_keys, void* d_values, size_t n, int value_bytes, int begin_bit,
-                        int end_bit, uint32_t* d_perm_out, hipStream_t stream, bool nested = false)
+                        int end_bit, uint32_t* d_perm_out, hipStream_t stream, bool nested = false,
+                        const uint32_t* run_if = nullptr)
 {
+    // (run_if gates the key / index passes only: the nested callers that use it sort keys alone)
+    GRACE_REQUIRE(!run_if || (nested && !d_values), "sort: a gated sort moves no payload");
     GRACE_REQUIRE(n == 0 || d_keys, "sort: null keys");
     GRACE_REQUIRE(n < (size_t(1) << 32), "sort: at most 2^32 - 1 elements");
     GRACE_REQUIRE(begin_bit >= 0 && end_bit <= int(sizeof(Key) * 8) && begin_bit < end_bit,
                   "sort: bad bit range");
     GRACE_REQUIRE(!d_values || (value_bytes > 0 && value_bytes % 4 == 0),
                   "sort: value_bytes must be a positive multiple of 4");
-    if (d_values) GRACE_TRY(scene_invalidate_if_written(d_values)); // prepared trace scene: stale
+    if (d_values) {   // cached trace records over this array are stale (a hint: they are validated anyway)
+        GRACE_TRY(scene_invalidate_if_written(d_values));
+        GRACE_TRY(rays_invalidate_if_written(d_values));
+    }
     if (n <= 1) {
         if (n == 1 && d_perm_out) GRACE_TRY_HIP(hipMemsetAsync(d_perm_out, 0, 4, stream));
         return GRACE_OK;
@@ -250,22 +260,22 @@ grace_status sort_pairs(Key* d_keys, void* d_values, size_t n, int value_bytes, 
         const int bits = (end_bit - shift) < RADIX_BITS ? (end_bit - shift) : RADIX_BITS;
         const uint32_t mask = (1u << bits) - 1u;
         sort_hist_kernel<Key><<<n_tiles, SORT_BLOCK, 0, stream>>>(k_in, n, shift, mask, n_tiles,
-                                                                 counts);
+                                                                 counts, run_if);
         GRACE_CHECK_LAUNCH();
-        GRACE_TRY(exclusive_scan_u32(counts, counts, n_counts, scan_ws, nullptr, stream));
+        GRACE_TRY(exclusive_scan_u32(counts, counts, n_counts, scan_ws, nullptr, stream, run_if));
         if (first)
             sort_scatter_kernel<Key, true><<<n_tiles, SORT_BLOCK, 0, stream>>>(
-                k_in, nullptr, k_out, i_out, n, shift, mask, n_tiles, counts);
+                k_in, nullptr, k_out, i_out, n, shift, mask, n_tiles, counts, run_if);
         else
             sort_scatter_kernel<Key, false><<<n_tiles, SORT_BLOCK, 0, stream>>>(
-                k_in, i_in, k_out, i_out, n, shift, mask, n_tiles, counts);
+                k_in, i_in, k_out, i_out, n, shift, mask, n_tiles, counts, run_if);
         GRACE_CHECK_LAUNCH();
         first = false;
         Key* tk = k_in; k_in = k_out; k_out = tk;
         uint32_t* ti = i_in; i_in = i_out; i_out = ti;
     }
     // k_in / i_in now hold the sorted keys and their source indices.
-    if (k_in != d_keys)
+    if (k_in != d_keys && !run_if)     // (a gated sort's keys are scratch: only the permutation is kept)
         GRACE_TRY_HIP(hipMemcpyAsync(d_keys, k_in, n * sizeof(Key), hipMemcpyDeviceToDevice,
                                      stream));
     if (d_values) {
@@ -290,10 +300,10 @@ size_t sort_ws_bytes(size_t n, int key_bytes, int value_bytes)
 
 grace_status sort_pairs_u32_nested(uint32_t* d_keys, void* d_values, size_t n, int value_bytes,
                                    int begin_bit, int end_bit, uint32_t* d_perm,
-                                   hipStream_t stream)
+                                   hipStream_t stream, const uint32_t* run_if)
 {
     return sort_pairs<uint32_t>(d_keys, d_values, n, value_bytes, begin_bit, end_bit, d_perm,
-                                stream, true);
+                                stream, true, run_if);
 }
 
 grace_status sort_pairs_u64_nested(uint64_t* d_keys, void* d_values, size_t n, int value_bytes,

@@ -206,12 +206,39 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         const bool fast_b = MODE == MODE_CUMULATIVE && !ts.exact_integrals;
         const bool reorder = ts.ray_reorder && n_rays > 64;
         constexpr bool D4 = (MODE == MODE_COUNT_D4 || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4);
-        const bool cached = !D4 && ts.scene.valid && ts.scene.tri == (MODE == MODE_TRI)
-            && ts.scene.prims == static_cast<const void*>(a.spheres) && ts.scene.n_prims == n_spheres
-            && ts.scene.nodes == static_cast<const void*>(a.nodes) && ts.scene.n_nodes == n_nodes
-            && ts.scene.leaves == static_cast<const void*>(a.leaves);
+        // ---- which cached records does this call use?  (see trace_state.hpp) -------------------
+        // NONE: derive into the workspace (a scene / batch seen for the first time);  FILL: the
+        // same arrays as the previous call -- derive into the cache;  CHECK: cached -- validate by
+        // signature on the device, the gated pre-pass recomputes if stale;  TRUST: cached, and the
+        // caller has switched validation off.
+        enum { USE_NONE, USE_FILL, USE_CHECK, USE_TRUST };
+        auto decide = [&](const bool have, const bool pinned, const bool repeat) {
+            if (have) return ts.cache_validation ? USE_CHECK : USE_TRUST;
+            return (ts.cache_auto && repeat && !pinned) ? USE_FILL : USE_NONE;
+        };
+        int scene_use = USE_NONE, rays_use = USE_NONE;
+        SceneKey skey;
+        skey.kind = MODE == MODE_TRI ? 1 : 0;
+        skey.prims = a.spheres; skey.nodes = a.nodes; skey.leaves = a.leaves;
+        skey.n_prims = n_spheres; skey.n_nodes = n_nodes;
+        if (!D4 && MODE != MODE_STATS) {
+            scene_use = decide(ts.scene.valid && ts.scene.key == skey, ts.scene.valid && ts.scene.pinned,
+                               ts.scene.seen == skey);
+            ts.scene.seen = skey;
+            if (scene_use == USE_FILL && scene_cache_alloc(ts, skey) != GRACE_OK) scene_use = USE_NONE;   // (no memory: no cache)
+        }
+        RayKey rkey;
+        rkey.rays = a.rays; rkey.n = n_rays;
+        if (reorder) {
+            rays_use = decide(ts.rays.valid && ts.rays.key == rkey, ts.rays.valid && ts.rays.pinned,
+                              ts.rays.seen == rkey);
+            ts.rays.seen = rkey;
+            if (rays_use == USE_FILL && rays_cache_alloc(ts, rkey) != GRACE_OK) rays_use = USE_NONE;
+        }
+        const bool scene_cached = scene_use != USE_NONE, rays_cached = rays_use != USE_NONE;
+        const bool any_sig = scene_use == USE_FILL || scene_use == USE_CHECK || rays_use == USE_FILL || rays_use == USE_CHECK;
         const size_t n_clusters = (n_spheres + 63) / 64;
-        GRACE_TRY(frame.begin((cached ? 0 : Workspace::aligned((n_spheres + 4) * sizeof(float4))
+        GRACE_TRY(frame.begin((scene_cached ? 0 : Workspace::aligned((n_spheres + 4) * sizeof(float4))
                                                + Workspace::aligned((n_spheres + 4) * sizeof(float2))
                                                + Workspace::aligned(n_nodes * sizeof(int2))
                                                + Workspace::aligned((2 * n_clusters + 1) * sizeof(float4))
@@ -223,13 +250,35 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                                                    + Workspace::aligned(n_rays * 4) : 0)
                                    + (MODE == MODE_CUMULATIVE ? Workspace::aligned(n_rays * SUM_CLASSES * 4) : 0)
                                    + (reorder ? 2 * Workspace::aligned(n_rays * 4)
-                                                + sort_ws_bytes(n_rays, 4, 0) : 0) + 1024, stream));
-        if (cached) {
-            a.A = ts.scene.A;
-            a.B = need_b ? (fast_b ? ts.scene.B50 : ts.scene.B1) : nullptr;
-            a.T64 = ts.scene.T64;
-            a.node_prims = ts.scene.node_prims;
-            a.C = ts.scene.C;
+                                                + sort_ws_bytes(n_rays, 4, 0) : 0)
+                                   + (any_sig ? Workspace::aligned(sig_partial_words() * 8) : 0) + 1024, stream));
+        if (any_sig) {
+            SigRequest rq;
+            if (scene_use == USE_FILL || scene_use == USE_CHECK) {
+                rq.prims = a.spheres; rq.prims_bytes = n_spheres * (MODE == MODE_TRI ? 36 : 16);
+                rq.nodes = a.nodes; rq.nodes_bytes = n_nodes * 64;
+                rq.leaves = a.leaves; rq.leaves_bytes = (n_nodes + 1) * 16;
+                rq.scene_ctl = ts.scene.ctl; rq.scene_force = scene_use == USE_FILL;
+            }
+            if (rays_use == USE_FILL || rays_use == USE_CHECK) {
+                rq.rays = a.rays; rq.rays_bytes = n_rays * 28;
+                rq.rays_ctl = ts.rays.ctl; rq.rays_force = rays_use == USE_FILL; rq.rays_ext = ts.rays.ext;
+            }
+            GRACE_TRY(launch_signatures(rq, Workspace::take<unsigned long long>(sig_partial_words()), stream));
+        }
+        if (scene_cached) {
+            Scene& sc = ts.scene;
+            if (scene_use != USE_TRUST) {
+                // (gated by the cache's stale flag: a first fill is forced stale)
+                GRACE_TRY(scene_fill(skey.kind, a.spheres, n_spheres, a.nodes, n_nodes, a.leaves, sc.A, sc.B1, sc.B50,
+                                     sc.T64, sc.node_prims, sc.C, stream, &sc.ctl->stale));
+                sc.valid = true;
+            }
+            a.A = sc.A;
+            a.B = need_b ? (fast_b ? sc.B50 : sc.B1) : nullptr;
+            a.T64 = sc.T64;
+            a.node_prims = sc.node_prims;
+            a.C = sc.C;
         } else {
             float4* A = Workspace::take<float4>(n_spheres + 4);
             float2* B = need_b ? Workspace::take<float2>(n_spheres + 4) : nullptr;
@@ -278,13 +327,20 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             constexpr bool lat_mode = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
             uint32_t* lat_flag = lat_mode ? ext + 13 : nullptr;
             int* split_dev = dev_split ? reinterpret_cast<int*>(ext + 12) : nullptr;
-            if (ts.rays.valid && ts.rays.rays == a.rays && ts.rays.n == n_rays) {
-                // prepared ray batch: only this call's device-side choices remain
+            if (rays_cached) {
+                RayOrder& ro = ts.rays;
+                if (rays_use != USE_TRUST) {
+                    // (gated by the cache's stale flag; the order lands in the cache's own buffers)
+                    GRACE_TRY(ray_order(a.rays, n_rays, ro.ext, keys, ro.perm, nullptr, nullptr, 0, 0, nullptr,
+                                        stream, &ro.ctl->stale));
+                    ro.valid = true;
+                }
+                // cached order: only this call's device-side choices remain
                 if (lat_flag || split_dev) {
-                    GRACE_TRY(launch_choose_variants(ts.rays.ext, int(n_rays), a.C + 2 * n_clusters, lat_flag,
+                    GRACE_TRY(launch_choose_variants(ro.ext, int(n_rays), a.C + 2 * n_clusters, lat_flag,
                                                      n_packets, split, split_dev, stream));
                 }
-                a.perm = ts.rays.perm;
+                a.perm = ro.perm;
             } else {
                 GRACE_TRY(ray_order(a.rays, n_rays, ext, keys, perm, a.C + 2 * n_clusters, lat_flag, n_packets,
                                     split, split_dev, stream));
@@ -445,7 +501,8 @@ grace_status rays_invalidate_if_written(const void* d_written)
     GRACE_TRY(current_context(&c));
     if (!c->trace) return GRACE_OK;
     TraceState& ts = *c->trace;
-    if (ts.rays.valid && d_written && d_written == static_cast<const void*>(ts.rays.rays)) return rays_release(ts);
+    if (ts.cache_validation) return GRACE_OK;     // validated before every use: nothing to drop eagerly
+    if (ts.rays.valid && d_written && d_written == static_cast<const void*>(ts.rays.key.rays)) return rays_release(ts);
     return GRACE_OK;
 }
 
@@ -455,8 +512,9 @@ grace_status scene_invalidate_if_written(const void* d_written)
     GRACE_TRY(current_context(&c));
     if (!c->trace) return GRACE_OK;
     TraceState& ts = *c->trace;
+    if (ts.cache_validation) return GRACE_OK;
     if (ts.scene.valid && d_written
-        && (d_written == ts.scene.prims || d_written == ts.scene.nodes || d_written == ts.scene.leaves))
+        && (d_written == ts.scene.key.prims || d_written == ts.scene.key.nodes || d_written == ts.scene.key.leaves))
         return scene_release(ts);
     return GRACE_OK;
 }
@@ -752,6 +810,20 @@ grace_status grace_trace_set_ray_reorder(int enabled)
 {
     GRACE_TRACE_STATE();
     ts.ray_reorder = enabled != 0;
+    return GRACE_OK;
+}
+
+grace_status grace_trace_set_cache_validation(int enabled)
+{
+    GRACE_TRACE_STATE();
+    ts.cache_validation = enabled != 0;
+    return GRACE_OK;
+}
+
+grace_status grace_trace_set_cache_auto(int enabled)
+{
+    GRACE_TRACE_STATE();
+    ts.cache_auto = enabled != 0;
     return GRACE_OK;
 }
 

@@ -34,8 +34,10 @@ __global__ void ray_ext_init_kernel(uint32_t* __restrict__ ext16)
 }
 
 __global__ __launch_bounds__(256) void ray_extents_kernel(const float* __restrict__ rays, int n,
-                                                          uint32_t* __restrict__ ext12)
+                                                          uint32_t* __restrict__ ext12,
+                                                          const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     float lo[6], hi[6];
     float len_hi = -INFINITY;   // the longest ray (slot 15: choose_lattice's scale for one-origin batches)
 #pragma unroll
@@ -125,8 +127,10 @@ __device__ __forceinline__ uint32_t hilbert2d_15(uint32_t x, uint32_t y)
 // batch unfit sets it.
 __global__ __launch_bounds__(256) void ray_lattice_kernel(const float* __restrict__ rays, int n,
                                                           const uint32_t* __restrict__ ext12,
-                                                          uint32_t* __restrict__ flag)
+                                                          uint32_t* __restrict__ flag,
+                                                          const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     int dims[2] = { 0, 0 }, nvar = 0;
     float lo[2] = { 0.f, 0.f }, span[2] = { 0.f, 0.f };
     for (int k = 5; k >= 0; --k) {          // (the order ray_keys_kernel takes them in)
@@ -213,8 +217,10 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(const float* __restrict__
                                                        uint32_t* __restrict__ lat_flag,
                                                        int split_packets, int split_launched,
                                                        int* __restrict__ split_dev,
-                                                       const uint32_t* __restrict__ not_grid)
+                                                       const uint32_t* __restrict__ not_grid,
+                                                       const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     const bool z_order_2d = not_grid && *not_grid == 0u;   // a power-of-two pixel grid (ray_lattice_kernel)
     if (blockIdx.x == 0 && threadIdx.x == 0)
         choose_variants(ext12, n, scene_min, lat_flag, split_packets, split_launched, split_dev);
@@ -310,39 +316,58 @@ grace_status launch_choose_variants(const uint32_t* ext12, int n, const float4* 
     return GRACE_OK;
 }
 
-// Prepared ray batch (grace_trace_prepare_rays): the ray coherence order -- extents, keys, the
-// partial sort: ten small launches, ~0.08 ms, a seventh of a 1/8-image shard's call -- depends on
-// the rays alone.  The reference leaves ray ordering to the caller (its generators sort at
-// generation time, gen_rays.cuh:483,520,577,615); a caller that traces the SAME batch repeatedly
-// (a fixed camera over an evolving scene, a benchmark loop) computes it once here.  Keyed on
-// (pointer, count): the caller promises not to change the rays until grace_trace_release_rays();
-// this library's own ray generators drop the cache when they write to the array.
+static grace_status rays_free_buffers(RayOrder& ro)
+{
+    if (ro.perm || ro.ext || ro.ctl) GRACE_TRY_HIP(hipDeviceSynchronize());
+    if (ro.perm) GRACE_TRY_HIP(hipFree(ro.perm));
+    if (ro.ext) GRACE_TRY_HIP(hipFree(ro.ext));
+    if (ro.ctl) GRACE_TRY_HIP(hipFree(ro.ctl));
+    ro.perm = nullptr; ro.ext = nullptr; ro.ctl = nullptr;
+    ro.valid = false;
+    ro.pinned = false;
+    return GRACE_OK;
+}
 
 grace_status rays_release(TraceState& ts)
 {
-    if (ts.rays.perm || ts.rays.ext) GRACE_TRY_HIP(hipDeviceSynchronize());
-    if (ts.rays.perm) GRACE_TRY_HIP(hipFree(ts.rays.perm));
-    if (ts.rays.ext) GRACE_TRY_HIP(hipFree(ts.rays.ext));
+    GRACE_TRY(rays_free_buffers(ts.rays));
     ts.rays = RayOrder();
+    return GRACE_OK;
+}
+
+grace_status rays_cache_alloc(TraceState& ts, const RayKey& key)
+{
+    RayOrder& ro = ts.rays;
+    GRACE_TRY(rays_free_buffers(ro));
+    if (hipMalloc(reinterpret_cast<void**>(&ro.perm), key.n * 4) != hipSuccess
+        || hipMalloc(reinterpret_cast<void**>(&ro.ext), 64) != hipSuccess
+        || hipMalloc(reinterpret_cast<void**>(&ro.ctl), sizeof(CacheCtl)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)rays_free_buffers(ro);
+        return set_error(GRACE_OUT_OF_MEMORY, __FILE__, __LINE__, "ray order cache: out of device memory");
+    }
+    ro.key = key;
     return GRACE_OK;
 }
 
 grace_status ray_order(const float* d_rays, size_t n_rays, uint32_t* ext, uint32_t* keys, uint32_t* perm,
                        const float4* scene_min, uint32_t* lat_flag, int n_packets, int split, int* split_dev,
-                       hipStream_t stream)
+                       hipStream_t stream, const uint32_t* run_if)
 {
     // minima at the top of the order, maxima / per-call choices / grid flag at zero: one tiny launch
-    // (two hipMemsetAsync of 24 and 40 bytes became four fill kernels)
-    ray_ext_init_kernel<<<1, 64, 0, stream>>>(ext);
+    // (a gated pass finds its extents initialised by the signature check)
+    if (!run_if) {
+        ray_ext_init_kernel<<<1, 64, 0, stream>>>(ext);
+        GRACE_CHECK_LAUNCH();
+    }
+    const int grid_small = stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256;
+    ray_extents_kernel<<<grid_small, 256, 0, stream>>>(d_rays, int(n_rays), ext, run_if);
     GRACE_CHECK_LAUNCH();
-    ray_extents_kernel<<<(stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256), 256, 0, stream>>>(
-        d_rays, int(n_rays), ext);
-    GRACE_CHECK_LAUNCH();
-    ray_lattice_kernel<<<(stream_grid(n_rays, 256, 8) < 256 ? stream_grid(n_rays, 256, 8) : 256), 256, 0, stream>>>(
-        d_rays, int(n_rays), ext, ext + 14);
+    ray_lattice_kernel<<<grid_small, 256, 0, stream>>>(d_rays, int(n_rays), ext, ext + 14, run_if);
     GRACE_CHECK_LAUNCH();
     ray_keys_kernel<<<stream_grid(n_rays, 256), 256, 0, stream>>>(d_rays, int(n_rays), ext, keys, scene_min,
-                                                                 lat_flag, n_packets, split, split_dev, ext + 14);
+                                                                 lat_flag, n_packets, split, split_dev, ext + 14,
+                                                                 run_if);
     GRACE_CHECK_LAUNCH();
     // Only the key bits that decide which PACKET a ray joins need sorting: the order of
     // the rays inside a packet is irrelevant (log2(packets) + 2 bits, in whole 8-bit
@@ -353,35 +378,40 @@ grace_status ray_order(const float* d_rays, size_t n_rays, uint32_t* ext, uint32
     while ((size_t(1) << (want_bits - 2)) < packets64 && want_bits < 30) ++want_bits;
     want_bits = ((want_bits + 7) / 8) * 8;
     const int begin_bit = want_bits >= 30 ? 0 : 30 - want_bits;
-    return sort_pairs_u32_nested(keys, nullptr, n_rays, 0, begin_bit, 30, perm, stream);
+    return sort_pairs_u32_nested(keys, nullptr, n_rays, 0, begin_bit, 30, perm, stream, run_if);
 }
 
+// grace_trace_prepare_rays: the cache filled NOW (and kept until released or replaced by another
+// prepare), instead of at the second call on the same batch.  The reference leaves ray ordering to
+// the caller (its generators sort at generation time, gen_rays.cuh:483,520,577,615).
 grace_status rays_prepare(TraceState& ts, const float* d_rays, size_t n_rays, hipStream_t stream)
 {
     GRACE_REQUIRE(d_rays || n_rays == 0, "trace_prepare_rays: null pointer");
     GRACE_REQUIRE(n_rays < (size_t(1) << 31), "trace_prepare_rays: bad ray count");
     GRACE_TRY(rays_release(ts));
     if (n_rays <= 64) return GRACE_OK;          // one packet: nothing to order
-    RayOrder ro;
-    if (hipMalloc(reinterpret_cast<void**>(&ro.perm), n_rays * 4) != hipSuccess
-        || hipMalloc(reinterpret_cast<void**>(&ro.ext), 64) != hipSuccess) {
-        if (ro.perm) (void)hipFree(ro.perm);
-        return set_error(GRACE_OUT_OF_MEMORY, __FILE__, __LINE__, "trace_prepare_rays: out of device memory");
-    }
-    ts.rays = ro;
+    RayKey key;
+    key.rays = d_rays; key.n = n_rays;
+    GRACE_TRY(rays_cache_alloc(ts, key));
+    RayOrder& ro = ts.rays;
     FrameGuard frame;
-    grace_status st = frame.begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 0) + 1024, stream);
+    grace_status st = frame.begin(Workspace::aligned(n_rays * 4) + sort_ws_bytes(n_rays, 4, 0)
+                                      + Workspace::aligned(sig_partial_words() * 8) + 1024, stream);
+    if (st == GRACE_OK) {
+        unsigned long long* partial = Workspace::take<unsigned long long>(sig_partial_words());
+        SigRequest rq;
+        rq.rays = d_rays; rq.rays_bytes = n_rays * 28;
+        rq.rays_ctl = ro.ctl; rq.rays_force = true; rq.rays_ext = ro.ext;
+        st = launch_signatures(rq, partial, stream);
+    }
     if (st == GRACE_OK) {
         uint32_t* keys = Workspace::take<uint32_t>(n_rays);
-        st = ray_order(d_rays, n_rays, ro.ext, keys, ro.perm, nullptr, nullptr, 0, 0, nullptr, stream);
+        st = ray_order(d_rays, n_rays, ro.ext, keys, ro.perm, nullptr, nullptr, 0, 0, nullptr, stream, &ro.ctl->stale);
     }
-    if (st != GRACE_OK) { rays_release(ts); return st; }
-    // (a one-time call: wait for the order, so that traces on ANY stream may use it)
-    if (hipStreamSynchronize(stream) != hipSuccess) {
-        rays_release(ts);
-        return set_error(GRACE_HIP_ERROR, __FILE__, __LINE__, "trace_prepare_rays: stream synchronisation failed");
-    }
-    ts.rays.valid = true; ts.rays.rays = d_rays; ts.rays.n = n_rays;
+    if (st != GRACE_OK) { (void)rays_release(ts); return st; }
+    ro.valid = true;
+    ro.pinned = true;
+    ts.rays.seen = key;
     return GRACE_OK;
 }
 

@@ -66,33 +66,36 @@ __device__ __forceinline__ void publish_r2_min(const float wave_r2_min, float4* 
 
 // C != null: the cluster boxes in the same pass (a wave's 64 consecutive records ARE a cluster:
 // the loop stride is a multiple of the workgroup size) -- one launch and one read of A fewer.
+// B1 = {1/h, 1/h^2} (the reference's per-hit arithmetic), B50 = {50/h, 1/h^2} (the fast integral's
+// table position): either or both.
 __global__ __launch_bounds__(256) void trace_prepass_kernel(const float4* __restrict__ spheres,
                                                             size_t n, float4* __restrict__ A,
-                                                            float2* __restrict__ B,
-                                                            const float b_scale,
-                                                            float4* __restrict__ C = nullptr)
+                                                            float2* __restrict__ B1,
+                                                            float2* __restrict__ B50,
+                                                            float4* __restrict__ C,
+                                                            const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     float wave_r2_min = INFINITY;
     // (whole waves enter every iteration: the bound is rounded up to the wave's first record)
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; (i & ~size_t(63)) < n + 4;
          i += size_t(gridDim.x) * blockDim.x) {
 
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        float2 b = make_float2(0.f, 0.f);
+        float2 b1 = make_float2(0.f, 0.f), b50 = b1;
         if (i < n) {
             const float4 s = spheres[i];
             a = make_float4(s.x, s.y, s.z, s.w * s.w); // sphere.w * sphere.w, intersect.h:37
-            if (B) {
-                const float ir = 1.f / s.w;            // functors/trace.cuh:181
-                b = make_float2(ir * b_scale, ir * ir); // functors/trace.cuh:184 (b_scale 1, or 50: fast)
-                // The fast integral's branch-free rounds add (table value 0) * (1/h^2) for a
-                // candidate the ray misses: keep that product 0 when 1/h^2 overflows (h < 5e-20).
-                if (b_scale != 1.0f) b.y = fminf(b.y, 3.4028234664e38f);
-            }
+            const float ir = 1.f / s.w;                // functors/trace.cuh:181
+            b1 = make_float2(ir, ir * ir);             // functors/trace.cuh:184
+            // The fast integral's branch-free rounds add (table value 0) * (1/h^2) for a
+            // candidate the ray misses: keep that product 0 when 1/h^2 overflows (h < 5e-20).
+            b50 = make_float2(ir * float(N_TABLE - 1), fminf(ir * ir, 3.4028234664e38f));
         }
         if (i < n + 4) {
             A[i] = a;
-            if (B) B[i] = b;
+            if (B1) B1[i] = b1;
+            if (B50) B50[i] = b50;
         }
         // (wave-uniform condition: every lane of the wave takes part in the shuffles)
         if (C && (i & ~size_t(63)) < n) wave_r2_min = fminf(wave_r2_min, cluster_box_of_wave(a, i < n, i >> 6, C));
@@ -132,8 +135,10 @@ __global__ __launch_bounds__(256) void trace_prepass_d4_kernel(const double* __r
 // (q = fl(s - o), b2 = fl(fl(q1^2) + fl(q2^2)) < h^2 admits |s - o| up to h (1 + 3 u) + u |s|).
 // A = {x, y, z, r^2} as written by the pre-passes (spheres: r = h; triangles: bounding radius).
 __global__ __launch_bounds__(256) void cluster_boxes_kernel(const float4* __restrict__ A, size_t n,
-                                                            float4* __restrict__ C)
+                                                            float4* __restrict__ C,
+                                                            const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     const size_t n_clusters = (n + 63) / 64;
     const int lane = threadIdx.x & 63;
     float wave_r2_min = INFINITY;   // over the clusters this wave handles
@@ -154,8 +159,10 @@ __global__ __launch_bounds__(256) void cluster_boxes_kernel(const float4* __rest
 // float operands, tests/helper/vector_math.cu:27-52; widening once is exact).
 __global__ __launch_bounds__(256) void tri_prepass_kernel(const float* __restrict__ tris, size_t n,
                                                           float4* __restrict__ A,
-                                                          double* __restrict__ T64)
+                                                          double* __restrict__ T64,
+                                                          const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n + 4;
          i += size_t(gridDim.x) * blockDim.x) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -190,8 +197,10 @@ __global__ __launch_bounds__(256) void tri_prepass_kernel(const float* __restric
 __global__ __launch_bounds__(256) void node_prims_kernel(const int4* __restrict__ nodes4,
                                                          const int4* __restrict__ leaves, int n_nodes,
                                                          int2* __restrict__ out,
-                                                         uint32_t* __restrict__ r2_min_slot)
+                                                         uint32_t* __restrict__ r2_min_slot,
+                                                         const uint32_t* __restrict__ run_if)
 {
+    if (run_if && *run_if == 0u) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // (the slot the cluster-box pass reduces the scene's smallest r^2 into starts out huge: this
     // launch precedes that pass on the stream)
@@ -207,81 +216,113 @@ __global__ __launch_bounds__(256) void node_prims_kernel(const int4* __restrict_
 namespace grace_hip {
 
 
-grace_status scene_release(TraceState& ts)
+static grace_status scene_free_buffers(Scene& sc)
 {
-    if (ts.scene.A || ts.scene.B1 || ts.scene.B50 || ts.scene.T64 || ts.scene.node_prims || ts.scene.C)
-        GRACE_TRY_HIP(hipDeviceSynchronize());
-    void* bufs[] = { ts.scene.A, ts.scene.B1, ts.scene.B50, ts.scene.T64, ts.scene.node_prims, ts.scene.C };
+    void* bufs[] = { sc.A, sc.B1, sc.B50, sc.T64, sc.node_prims, sc.C, sc.ctl };
+    bool any = false;
+    for (void* b : bufs) any = any || b;
+    if (any) GRACE_TRY_HIP(hipDeviceSynchronize());
     for (void* b : bufs)
         if (b) GRACE_TRY_HIP(hipFree(b));
+    sc.A = nullptr; sc.B1 = sc.B50 = nullptr; sc.T64 = nullptr; sc.node_prims = nullptr; sc.C = nullptr;
+    sc.ctl = nullptr;
+    sc.valid = false;
+    sc.pinned = false;
+    return GRACE_OK;
+}
+
+grace_status scene_release(TraceState& ts)
+{
+    GRACE_TRY(scene_free_buffers(ts.scene));
     ts.scene = Scene();
     return GRACE_OK;
 }
 
-grace_status scene_fill(int kind, const void* prims, size_t n_prims, const float4* nodes,
-                        size_t n_nodes, const int4* leaves, float4* A, float2* B1, float2* B50,
-                        double* T64, int2* node_prims, float4* C, hipStream_t stream)
+grace_status scene_cache_alloc(TraceState& ts, const SceneKey& key)
 {
-    node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
-        reinterpret_cast<const int4*>(nodes), leaves, int(n_nodes), node_prims,
-        reinterpret_cast<uint32_t*>(C + 2 * ((n_prims + 63) / 64)));
-    GRACE_CHECK_LAUNCH();
-    if (kind == 1) {
-        tri_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
-            static_cast<const float*>(prims), n_prims, A, T64);
-        GRACE_CHECK_LAUNCH();
-    } else if (kind == 2) {
-        trace_prepass_d4_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
-            static_cast<const double*>(prims), n_prims, A);
-        GRACE_CHECK_LAUNCH();
-    } else {
-        trace_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
-            static_cast<const float4*>(prims), n_prims, A, B1 ? B1 : B50,
-            B1 ? 1.0f : float(N_TABLE - 1), C);      // (+ the cluster boxes: fused)
-        GRACE_CHECK_LAUNCH();
-        if (B1 && B50) {
-            trace_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
-                static_cast<const float4*>(prims), n_prims, A, B50, float(N_TABLE - 1));
-            GRACE_CHECK_LAUNCH();
-        }
-    }
-    if (kind != 0) {
-        cluster_boxes_kernel<<<stream_grid((n_prims + 63) / 64, 4), 256, 0, stream>>>(A, n_prims, C);
-        GRACE_CHECK_LAUNCH();
-    }
-    return GRACE_OK;
-}
-
-grace_status scene_prepare(TraceState& ts, bool tri, const void* prims, size_t n_prims,
-                           const int* d_nodes, size_t n_nodes, const int* d_leaves, hipStream_t stream)
-{
-    GRACE_REQUIRE(prims && d_nodes && d_leaves, "trace_prepare: null pointer");
-    GRACE_REQUIRE(n_prims > 0 && n_nodes >= 1, "trace_prepare: empty scene");
-    GRACE_TRY(scene_release(ts));
-    Scene sc;
+    Scene& sc = ts.scene;
+    GRACE_TRY(scene_free_buffers(sc));
+    const bool tri = key.kind == 1;
     auto alloc = [&](void** ptr, size_t bytes) -> grace_status {
         hipError_t e = hipMalloc(ptr, bytes);
         if (e != hipSuccess)
             return set_error(GRACE_OUT_OF_MEMORY, __FILE__, __LINE__, hipGetErrorString(e));
         return GRACE_OK;
     };
+    const size_t n_prims = key.n_prims;
     grace_status st = alloc(reinterpret_cast<void**>(&sc.A), (n_prims + 4) * sizeof(float4));
     if (st == GRACE_OK && !tri) st = alloc(reinterpret_cast<void**>(&sc.B1), (n_prims + 4) * sizeof(float2));
     if (st == GRACE_OK && !tri) st = alloc(reinterpret_cast<void**>(&sc.B50), (n_prims + 4) * sizeof(float2));
     if (st == GRACE_OK && tri) st = alloc(reinterpret_cast<void**>(&sc.T64), 72 * (n_prims + 4));
-    if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.node_prims), n_nodes * sizeof(int2));
+    if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.node_prims), key.n_nodes * sizeof(int2));
     if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.C), (2 * ((n_prims + 63) / 64) + 1) * sizeof(float4));
-    ts.scene = sc;   // so that a failure below releases what was allocated
-    if (st != GRACE_OK) { scene_release(ts); return st; }
-    st = scene_fill(tri ? 1 : 0, prims, n_prims, reinterpret_cast<const float4*>(d_nodes), n_nodes,
-                    reinterpret_cast<const int4*>(d_leaves), sc.A, sc.B1, sc.B50, sc.T64,
-                    sc.node_prims, sc.C, stream);
-    if (st != GRACE_OK) { scene_release(ts); return st; }
-    // (a one-time call: wait for the records, so that traces on ANY stream may use them)
-    GRACE_TRY_HIP(hipStreamSynchronize(stream));
-    ts.scene.valid = true; ts.scene.tri = tri;
-    ts.scene.prims = prims; ts.scene.nodes = d_nodes; ts.scene.leaves = d_leaves;
-    ts.scene.n_prims = n_prims; ts.scene.n_nodes = n_nodes;
+    if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.ctl), sizeof(CacheCtl));
+    if (st != GRACE_OK) { (void)scene_free_buffers(sc); return st; }
+    sc.key = key;
+    return GRACE_OK;
+}
+
+grace_status scene_fill(int kind, const void* prims, size_t n_prims, const float4* nodes,
+                        size_t n_nodes, const int4* leaves, float4* A, float2* B1, float2* B50,
+                        double* T64, int2* node_prims, float4* C, hipStream_t stream,
+                        const uint32_t* run_if)
+{
+    node_prims_kernel<<<ceil_div(n_nodes, 256), 256, 0, stream>>>(
+        reinterpret_cast<const int4*>(nodes), leaves, int(n_nodes), node_prims,
+        reinterpret_cast<uint32_t*>(C + 2 * ((n_prims + 63) / 64)), run_if);
+    GRACE_CHECK_LAUNCH();
+    if (kind == 1) {
+        tri_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
+            static_cast<const float*>(prims), n_prims, A, T64, run_if);
+        GRACE_CHECK_LAUNCH();
+    } else if (kind == 2) {
+        trace_prepass_d4_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
+            static_cast<const double*>(prims), n_prims, A);
+        GRACE_CHECK_LAUNCH();
+    } else {
+        // (+ the cluster boxes: fused)
+        trace_prepass_kernel<<<stream_grid(n_prims + 4, 256), 256, 0, stream>>>(
+            static_cast<const float4*>(prims), n_prims, A, B1, B50, C, run_if);
+        GRACE_CHECK_LAUNCH();
+    }
+    if (kind != 0) {
+        cluster_boxes_kernel<<<stream_grid((n_prims + 63) / 64, 4), 256, 0, stream>>>(A, n_prims, C, run_if);
+        GRACE_CHECK_LAUNCH();
+    }
+    return GRACE_OK;
+}
+
+// grace_trace_prepare_f4 / _tri: the cache filled NOW (and kept until released or replaced by
+// another prepare), instead of at the second call on the same arrays.
+grace_status scene_prepare(TraceState& ts, bool tri, const void* prims, size_t n_prims,
+                           const int* d_nodes, size_t n_nodes, const int* d_leaves, hipStream_t stream)
+{
+    GRACE_REQUIRE(prims && d_nodes && d_leaves, "trace_prepare: null pointer");
+    GRACE_REQUIRE(n_prims > 0 && n_nodes >= 1, "trace_prepare: empty scene");
+    SceneKey key;
+    key.kind = tri ? 1 : 0; key.prims = prims; key.nodes = d_nodes; key.leaves = d_leaves;
+    key.n_prims = n_prims; key.n_nodes = n_nodes;
+    GRACE_TRY(scene_cache_alloc(ts, key));
+    Scene& sc = ts.scene;
+    FrameGuard frame;
+    grace_status st = frame.begin(Workspace::aligned(sig_partial_words() * 8) + 1024, stream);
+    if (st == GRACE_OK) {
+        unsigned long long* partial = Workspace::take<unsigned long long>(sig_partial_words());
+        SigRequest rq;
+        rq.prims = prims; rq.prims_bytes = n_prims * (tri ? 36 : 16);
+        rq.nodes = d_nodes; rq.nodes_bytes = n_nodes * 64;
+        rq.leaves = d_leaves; rq.leaves_bytes = (n_nodes + 1) * 16;
+        rq.scene_ctl = sc.ctl; rq.scene_force = true;
+        st = launch_signatures(rq, partial, stream);
+    }
+    if (st == GRACE_OK)
+        st = scene_fill(tri ? 1 : 0, prims, n_prims, reinterpret_cast<const float4*>(d_nodes), n_nodes,
+                        reinterpret_cast<const int4*>(d_leaves), sc.A, sc.B1, sc.B50, sc.T64,
+                        sc.node_prims, sc.C, stream);
+    if (st != GRACE_OK) { (void)scene_release(ts); return st; }
+    sc.valid = true;
+    sc.pinned = true;
+    ts.scene.seen = key;
     return GRACE_OK;
 }
 

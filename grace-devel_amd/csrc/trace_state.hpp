@@ -74,25 +74,62 @@ struct TraceArgs {
 };
 
 
-// ---- scene-constant pre-pass data (trace_prepass.hip) ------------------------------------------
-// A, B, the nodes' primitive spans and the cluster boxes depend on the primitives and the tree
-// only.  A trace call derives them into the workspace, or -- when the same scene is traced again --
-// finds them in the context's cache (see launch_trace).
-struct Scene {
-    bool valid = false, tri = false;
-    const void* prims = nullptr; const void* nodes = nullptr; const void* leaves = nullptr;
-    size_t n_prims = 0, n_nodes = 0;
-    float4* A = nullptr; float2* B1 = nullptr; float2* B50 = nullptr; double* T64 = nullptr;
-    int2* node_prims = nullptr; float4* C = nullptr;
+// ---- cached records and their validation (trace_cache.hip) -----------------------------------
+// A trace call is stateless for its caller -- trace(rays, spheres, tree) like the reference's --
+// but most callers trace the same scene, or the same rays, again and again (frames of a camera
+// path over one snapshot; one ray batch over an evolving simulation).  The records a call derives
+// from its inputs alone are therefore kept per context: when the arrays of a call are those of
+// the previous one (same pointers and sizes), the call after that finds their records cached.
+// A cached record is NEVER trusted on pointer equality: every use first re-reads the inputs
+// through a 128-bit signature kernel (one streaming pass, HBM-bound, ~1/5 of the cost of
+// re-deriving the records) and compares it ON THE DEVICE with the signature the records were
+// derived from; if they differ the (flag-gated) pre-pass kernels recompute the records in place.
+// No host round trip either way.  grace_trace_set_cache_validation(0) lets a caller who promises
+// not to modify cached arrays skip the signature pass.
+struct CacheCtl {                 // device memory, one per cache
+    unsigned long long sig[2];    // signature of the inputs the cached records were derived from
+    uint32_t stale;               // set by the check kernel of the current call: recompute
+    uint32_t pad;
 };
 
-// ---- ray coherence order (trace_coherence.hip) -------------------------------------------------
-struct RayOrder {
-    bool valid = false;
+struct SceneKey {
+    int kind = -1;                // 0 float4 spheres, 1 triangles
+    const void* prims = nullptr; const void* nodes = nullptr; const void* leaves = nullptr;
+    size_t n_prims = 0, n_nodes = 0;
+    bool operator==(const SceneKey& o) const
+    {
+        return kind == o.kind && prims == o.prims && nodes == o.nodes && leaves == o.leaves
+            && n_prims == o.n_prims && n_nodes == o.n_nodes;
+    }
+};
+
+// Scene-constant pre-pass data (trace_prepass.hip): A, B, the nodes' primitive spans and the
+// cluster boxes depend on the primitives and the tree only.
+struct Scene {
+    bool valid = false;           // the buffers hold the records of `key`
+    SceneKey key;
+    SceneKey seen;                // the previous call's scene (a repeat is what gets cached)
+    float4* A = nullptr; float2* B1 = nullptr; float2* B50 = nullptr; double* T64 = nullptr;
+    int2* node_prims = nullptr; float4* C = nullptr;
+    CacheCtl* ctl = nullptr;
+    bool pinned = false;          // filled by grace_trace_prepare_*: kept until released / replaced
+};
+
+struct RayKey {
     const float* rays = nullptr;
     size_t n = 0;
-    uint32_t* perm = nullptr;   // n
-    uint32_t* ext = nullptr;    // 12 extents (order-preserving uints: minima then maxima of d, o)
+    bool operator==(const RayKey& o) const { return rays == o.rays && n == o.n; }
+};
+
+// Ray coherence order (trace_coherence.hip).
+struct RayOrder {
+    bool valid = false;
+    RayKey key, seen;
+    uint32_t* perm = nullptr;     // n
+    uint32_t* ext = nullptr;      // 16 words: 12 extents (order-preserving uints: minima then maxima
+                                  // of d, o), [14] not-a-grid flag, [15] longest ray
+    CacheCtl* ctl = nullptr;
+    bool pinned = false;
 };
 
 // trace_sph walks twice -- hit counts (for the offsets), then the per-hit pass -- and the split
@@ -126,6 +163,8 @@ struct TraceState {
     int width = -1;                        // rays per packet of the per-hit / triangle traces; -1: automatic
     bool exact_integrals = false;          // column-density trace: bit-reproducible per-hit arithmetic
     bool hits_stage_split = true;          // split per-hit walk: stage heavy packets' hits in LDS
+    bool cache_validation = true;          // validate cached records by signature before every use
+    bool cache_auto = true;                // cache the records of a scene / ray batch seen twice in a row
     Scene scene;
     RayOrder rays;
     HitsCache hits;
@@ -134,23 +173,48 @@ struct TraceState {
 // The TraceState of the calling thread's context (created on first use).
 grace_status trace_state(TraceState** out);
 
+// trace_cache.hip: signatures of the inputs behind cached records.
+// One launch reads up to four arrays -- the scene's primitives, nodes and leaves (group 0) and the
+// rays (group 1); a null array is skipped -- and leaves per-workgroup partial sums in `partial`
+// (sig_partial_words() 64-bit words of scratch); a second, single-workgroup launch folds them,
+// compares each requested group with its cache's stored signature, stores the new one and sets the
+// cache's stale flag (force: set it regardless -- a first fill).  A stale ray cache also gets its
+// extents re-initialised.
+size_t sig_partial_words();
+struct SigRequest {
+    const void* prims = nullptr; size_t prims_bytes = 0;
+    const void* nodes = nullptr; size_t nodes_bytes = 0;
+    const void* leaves = nullptr; size_t leaves_bytes = 0;
+    CacheCtl* scene_ctl = nullptr; bool scene_force = false;
+    const void* rays = nullptr; size_t rays_bytes = 0;
+    CacheCtl* rays_ctl = nullptr; bool rays_force = false;
+    uint32_t* rays_ext = nullptr;
+};
+grace_status launch_signatures(const SigRequest& rq, unsigned long long* partial, hipStream_t stream);
+
 // trace_prepass.hip
 grace_status scene_release(TraceState& ts);
+// Buffers of the scene cache for `key` (replaces whatever is cached).
+grace_status scene_cache_alloc(TraceState& ts, const SceneKey& key);
 // Fills the scene-constant arrays (any of B1 / B50 / T64 may be null).  kind: 0 float4 spheres,
-// 1 triangles, 2 double4 spheres.
+// 1 triangles, 2 double4 spheres.  run_if (device, optional): every kernel returns at once if
+// *run_if == 0.
 grace_status scene_fill(int kind, const void* prims, size_t n_prims, const float4* nodes,
                         size_t n_nodes, const int4* leaves, float4* A, float2* B1, float2* B50,
-                        double* T64, int2* node_prims, float4* C, hipStream_t stream);
+                        double* T64, int2* node_prims, float4* C, hipStream_t stream,
+                        const uint32_t* run_if = nullptr);
 grace_status scene_prepare(TraceState& ts, bool tri, const void* prims, size_t n_prims,
                            const int* d_nodes, size_t n_nodes, const int* d_leaves, hipStream_t stream);
 
 // trace_coherence.hip
 grace_status rays_release(TraceState& ts);
+grace_status rays_cache_alloc(TraceState& ts, const RayKey& key);
 // extents -> keys -> partial sort; keys: n words of scratch (the caller's workspace frame must
-// include sort_ws_bytes(n_rays, 4, 0))
+// include sort_ws_bytes(n_rays, 4, 0)).  run_if (device, optional): gates every kernel; the
+// extents must then have been initialised already (launch_signatures does it for a stale cache).
 grace_status ray_order(const float* d_rays, size_t n_rays, uint32_t* ext, uint32_t* keys, uint32_t* perm,
                        const float4* scene_min, uint32_t* lat_flag, int n_packets, int split, int* split_dev,
-                       hipStream_t stream);
+                       hipStream_t stream, const uint32_t* run_if = nullptr);
 grace_status rays_prepare(TraceState& ts, const float* d_rays, size_t n_rays, hipStream_t stream);
 // The device-side choices of a trace launch for a batch whose order is cached.
 grace_status launch_choose_variants(const uint32_t* ext12, int n, const float4* scene_min, uint32_t* lat_flag,

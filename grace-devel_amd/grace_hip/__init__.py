@@ -319,6 +319,16 @@ def set_exact_integrals(enabled):
     _check(_lib.grace_trace_set_exact_integrals(C.c_int(1 if enabled else 0)))
 
 
+def set_cache_validation(enabled):
+    """1 (default): cached scene / ray records are validated by signature before every use."""
+    _check(_lib.grace_trace_set_cache_validation(C.c_int(1 if enabled else 0)))
+
+
+def set_cache_auto(enabled):
+    """1 (default): the records of a scene / ray batch given twice in a row are cached."""
+    _check(_lib.grace_trace_set_cache_auto(C.c_int(1 if enabled else 0)))
+
+
 def set_lattice_split(k):
     _check(_lib.grace_trace_set_lattice_split(C.c_int(k)))
 

@@ -223,22 +223,63 @@ GRACE_HOST void trace_with_sentinels_sph(
 }
 
 // ---- extensions (not in the reference) ------------------------------------------------------
-// Prepared scene and prepared ray batch: what every trace call otherwise recomputes from its
-// arguments (the scene's pre-pass records; the ray coherence order) is computed once for inputs
-// that are traced repeatedly.  Results never depend on it.  See grace_hip.h.
-GRACE_HOST inline void prepare_trace_sph(const thrust::device_vector<float4>& d_spheres, const Tree& d_tree)
+// What every trace call derives from its arguments alone -- the scene's pre-pass records, the ray
+// coherence order -- is cached by the library for arrays that are traced repeatedly (from the second
+// consecutive call on; see "Cached trace records" in grace_hip.h).  prepare_trace_sph /
+// prepare_trace_rays fill that cache NOW and pin it for as long as the returned handle lives.
+// Cached records are validated against the arrays' current contents before every use, so modifying
+// or reallocating d_spheres / d_tree / d_rays while a handle is alive is safe (it costs a
+// re-derivation); only grace_trace_set_cache_validation(0) turns that into the caller's promise.
+// Results never depend on any of this.
+class PreparedTrace
+{
+public:
+    PreparedTrace() : scene_(false), rays_(false) {}
+    PreparedTrace(PreparedTrace&& o) : scene_(o.scene_), rays_(o.rays_) { o.scene_ = o.rays_ = false; }
+    PreparedTrace& operator=(PreparedTrace&& o)
+    {
+        if (this != &o) { release(); scene_ = o.scene_; rays_ = o.rays_; o.scene_ = o.rays_ = false; }
+        return *this;
+    }
+    ~PreparedTrace() { release(); }
+    // Unpins and frees what this handle pinned (a later prepare_* may already have replaced it).
+    void release()
+    {
+        if (scene_) GRACE_STATUS_CHECK(grace_trace_release());
+        if (rays_) GRACE_STATUS_CHECK(grace_trace_release_rays());
+        scene_ = rays_ = false;
+    }
+
+private:
+    PreparedTrace(const PreparedTrace&);
+    PreparedTrace& operator=(const PreparedTrace&);
+    bool scene_, rays_;
+    friend PreparedTrace prepare_trace_sph(const thrust::device_vector<float4>&, const Tree&);
+    friend PreparedTrace prepare_trace_rays(const thrust::device_vector<Ray>&);
+};
+
+__attribute__((warn_unused_result))
+GRACE_HOST PreparedTrace prepare_trace_sph(const thrust::device_vector<float4>& d_spheres, const Tree& d_tree)
 {
     const detail::TreeArgs t = detail::tree_args(d_tree);
     GRACE_STATUS_CHECK(grace_trace_prepare_f4(reinterpret_cast<const float*>(detail::raw(d_spheres)),
                                               d_spheres.size(), t.nodes, t.n_nodes, t.leaves, NULL));
+    PreparedTrace h;
+    h.scene_ = true;
+    return h;
 }
 
-GRACE_HOST inline void prepare_trace_rays(const thrust::device_vector<Ray>& d_rays)
+__attribute__((warn_unused_result))
+GRACE_HOST PreparedTrace prepare_trace_rays(const thrust::device_vector<Ray>& d_rays)
 {
     GRACE_STATUS_CHECK(grace_trace_prepare_rays(detail::raw(d_rays), d_rays.size(), NULL));
+    PreparedTrace h;
+    h.rays_ = true;
+    return h;
 }
 
-GRACE_HOST inline void release_prepared_trace()
+// Drops whatever the calling thread's context has cached or pinned.
+GRACE_HOST void release_prepared_trace()
 {
     GRACE_STATUS_CHECK(grace_trace_release());
     GRACE_STATUS_CHECK(grace_trace_release_rays());

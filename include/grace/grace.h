@@ -600,15 +600,51 @@ inline void trace_cumulative_sph(const device_vector<Ray>& d_rays,
 // Extensions (not in the reference; see grace_hip.h): what every trace call otherwise recomputes
 // from its arguments -- the scene's pre-pass records, the ray coherence order -- computed once for
 // inputs that are traced repeatedly.  Results never depend on it.
-inline void prepare_trace_sph(const device_vector<float4>& d_spheres, const Tree& d_tree)
+// The returned handle pins the cached records while it lives; they are validated against the
+// arrays' current contents before every use (see "Cached trace records" in grace_hip.h).
+class PreparedTrace
+{
+public:
+    PreparedTrace() : scene_(false), rays_(false) {}
+    PreparedTrace(PreparedTrace&& o) : scene_(o.scene_), rays_(o.rays_) { o.scene_ = o.rays_ = false; }
+    PreparedTrace& operator=(PreparedTrace&& o)
+    {
+        if (this != &o) { release(); scene_ = o.scene_; rays_ = o.rays_; o.scene_ = o.rays_ = false; }
+        return *this;
+    }
+    ~PreparedTrace() { release(); }
+    void release()
+    {
+        if (scene_) detail::check(grace_trace_release());
+        if (rays_) detail::check(grace_trace_release_rays());
+        scene_ = rays_ = false;
+    }
+
+private:
+    PreparedTrace(const PreparedTrace&);
+    PreparedTrace& operator=(const PreparedTrace&);
+    bool scene_, rays_;
+    friend PreparedTrace prepare_trace_sph(const device_vector<float4>&, const Tree&);
+    friend PreparedTrace prepare_trace_rays(const device_vector<Ray>&);
+};
+
+__attribute__((warn_unused_result))
+inline PreparedTrace prepare_trace_sph(const device_vector<float4>& d_spheres, const Tree& d_tree)
 {
     detail::check(grace_trace_prepare_f4(&d_spheres.data()->x, d_spheres.size(), &d_tree.nodes.data()->x,
                                          d_tree.leaves.size() - 1, &d_tree.leaves.data()->x, nullptr));
+    PreparedTrace h;
+    h.scene_ = true;
+    return h;
 }
 
-inline void prepare_trace_rays(const device_vector<Ray>& d_rays)
+__attribute__((warn_unused_result))
+inline PreparedTrace prepare_trace_rays(const device_vector<Ray>& d_rays)
 {
     detail::check(grace_trace_prepare_rays(d_rays.data(), d_rays.size(), nullptr));
+    PreparedTrace h;
+    h.rays_ = true;
+    return h;
 }
 
 inline void release_prepared_trace()

@@ -62,13 +62,13 @@ int main(int argc, char* argv[])
     // (the reference reduces on the device with thrust::reduce; a host loop here)
     thrust::host_vector<float> h_integrals = d_integrals;
 
-    // The extensions: the same trace with the scene and the ray batch prepared -- same bits.
+    // The extensions: the same trace with the scene and the ray batch prepared (handles pin the
+    // cached records while they live) -- same bits.
     {
-        grace::prepare_trace_sph(d_spheres, d_tree);
-        grace::prepare_trace_rays(d_rays);
+        grace::PreparedTrace scene = grace::prepare_trace_sph(d_spheres, d_tree);
+        grace::PreparedTrace rays = grace::prepare_trace_rays(d_rays);
         thrust::device_vector<float> d_again(N_rays);
         grace::trace_cumulative_sph(d_rays, d_spheres, d_tree, d_again);
-        grace::release_prepared_trace();
         thrust::host_vector<float> h_again = d_again;
         if (std::memcmp(thrust::raw_pointer_cast(h_again.data()), thrust::raw_pointer_cast(h_integrals.data()),
                         N_rays * sizeof(float)) != 0) {
