@@ -111,19 +111,17 @@ __device__ __forceinline__ float hit_integral(const float b2, const float ir, co
 
 // The column-density trace's default evaluation of the same line integral (tolerance, not
 // bit, parity -- DESIGN.md section 4): v_sqrt_f32 as is (1 ulp), table position
-// b = sqrt(b2) * (50/h) with 50/h from the pre-pass, weight v_fract_f32(b), fp32 FMA on an
-// fp32 (y_i, y_{i+1} - y_i) table rounded from the fp64 one.  lutf has N_TABLE + 1 entries,
-// the last two being (y_50, 0), so b == 50 (sqrt(b2)/h rounded up to 1) needs no clamp.
-// Eight VALU instructions instead of twenty-five; each term within ~3 ulp of the exact one.
+// b = sqrt(b2) * (50/h) with 50/h from the pre-pass, ONE fp32 FMA on an fp32 table of
+// (y_i - i dy_i, dy_i) rounded from the fp64 one: fma(dy_i, b, y_i - i dy_i), i = int(b).  Entries
+// from N_TABLE - 1 on are (0, 0), so b == 50 (sqrt(b2)/h rounded up to 1) needs no clamp.
+// Seven VALU instructions instead of twenty-five; each term within a few ulp of the exact one.
 // Returns the table value; the caller applies 1/h^2 inside its accumulating FMA.
 __device__ __forceinline__ float hit_integral_fast(const float b2, const float ir50,
                                                    const float2* lutf)
 {
     const float b = __builtin_amdgcn_sqrtf(b2) * ir50;
-    const int x_idx = static_cast<int>(b);
-    const float t = __builtin_amdgcn_fractf(b);
-    const float2 y = lutf[x_idx];
-    return __builtin_fmaf(t, y.y, y.x);
+    const float2 y = lutf[static_cast<int>(b)];
+    return __builtin_fmaf(y.y, b, y.x);
 }
 
 // Moeller-Trumbore with back-face culling, tests/profile_trace_triangle/triangle.cuh:54-88,
@@ -354,7 +352,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     }
     constexpr bool FAST = ALT && MODE == MODE_CUMULATIVE;
     __shared__ double2 s_lut[FAST ? 1 : N_TABLE];
-    __shared__ float2 s_lutf[FAST ? N_TABLE + 1 : 1];
+    // Fast integral: entry i = (y_i - i dy_i, dy_i), so that the lerp at table position b is ONE fma,
+    // fma(dy_i, b, y_i - i dy_i) with i = int(b) -- no fractional part to extract.  Entries from
+    // N_TABLE - 1 on are (0, 0): a position clamped to the table's end, or beyond it (misses of
+    // the test-free rounds), contributes exactly +0.
+    constexpr int LUTF_N = 256;
+    __shared__ float2 s_lutf[FAST ? LUTF_N : 1];
     // Per-wave tile of the candidates of the current culling round (MODE_TRI keeps its
     // fp64 triangles on the scalar path).
     constexpr bool D4 = (MODE == MODE_COUNT_D4 || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4);
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     // Three 8-byte planes per wave -- (x, y), (z, h^2), (1/h terms) -- so that one address
     // (plane base + 8 j) serves all of a survivor's reads through immediate offsets.
     // (66 slots: the survivor loop reads up to two slots past the round's last survivor)
-    __shared__ float2 s_tile[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 3 : 1][LDS_TILE ? 66 : 1];
+    __shared__ __align__(16) float2 s_tile[LDS_TILE ? TRACE_BLOCK / 64 : 1][LDS_TILE ? 3 : 1][LDS_TILE ? 66 : 1];
     // *_D4 modes: the round's candidates as doubles, lane-indexed: {x, y, z, w w, 1/w, (1/w)^2}
     // (the division is done once per candidate by its lane, not once per survivor by the wave).
     __shared__ double s_tile_d[D4 ? TRACE_BLOCK / 64 : 1][D4 ? 64 : 1][D4 ? 6 : 1];
@@ -386,12 +389,19 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     const int wave_id = __builtin_amdgcn_readfirstlane(vblock * (TRACE_BLOCK / 64)
                                                        + (threadIdx.x >> 6));
     if (MODE == MODE_CUMULATIVE || MODE == MODE_HITS || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4) {
-        if (threadIdx.x < N_TABLE + (FAST ? 1 : 0)) {
-            const int i0 = threadIdx.x < N_TABLE ? threadIdx.x : N_TABLE - 1;
+        if (FAST) {
+            static_assert(TRACE_BLOCK >= 256, "one table entry per thread");
+            float2 e = make_float2(0.f, 0.f);
+            if (threadIdx.x < N_TABLE - 1) {
+                const double y0 = c_kernel_table[threadIdx.x], dy = c_kernel_table[threadIdx.x + 1] - y0;
+                e = make_float2(float(y0 - double(threadIdx.x) * dy), float(dy));
+            }
+            if (threadIdx.x < LUTF_N) s_lutf[threadIdx.x] = e;
+        } else if (threadIdx.x < N_TABLE) {
+            const int i0 = threadIdx.x;
             const double y0 = c_kernel_table[i0];
             const double y1 = i0 + 1 < N_TABLE ? c_kernel_table[i0 + 1] : y0;
-            if (FAST) s_lutf[threadIdx.x] = make_float2(float(y0), float(y1 - y0));
-            else s_lut[threadIdx.x] = make_double2(y0, y1 - y0);
+            s_lut[threadIdx.x] = make_double2(y0, y1 - y0);
         }
         __syncthreads();
     }
@@ -526,6 +536,15 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     }
     const float o1 = axis == 0 ? oy : ox;
     const float o2 = axis == 2 ? oy : oz;
+    // Axis-aligned packets, fast integral: a sphere hit by SOME ray of the packet lies within
+    // h + D of every other ray (D = diagonal of the origins' box), i.e. at a table position below
+    // 50 (1 + D / h).  For h >= D / 3 that stays below 200 < LUTF_N: such survivors need no clamp.
+    float fat_r2 = INFINITY;
+    if (FAST && axis >= 0) {
+        const float ex = beam.ohi[0] - beam.olo[0], ey = beam.ohi[1] - beam.olo[1], ez = beam.ohi[2] - beam.olo[2];
+        const float e1 = axis == 0 ? ey : ex, e2 = axis == 2 ? ey : ez;
+        fat_r2 = (e1 * e1 + e2 * e2) * (1.0f / 9.0f) * 1.0001f;
+    }
     const int treelet = axis >= 0 ? a.treelet_axis : a.treelet;
     // Origin lattice of an axis-aligned packet.  The beam cull bounds b^2 at the point of the
     // origin RECTANGLE nearest to the sphere; a sphere smaller than the ray spacing can lie
@@ -772,7 +791,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
             auto sweep_range = [&](auto ax_tag) {
                 constexpr int AX = decltype(ax_tag)::value;
             constexpr bool NEED_B = (MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
+            constexpr bool LEAN4 = FAST && AX >= 0;
             const int wv = threadIdx.x >> 6;
+            float4* const tile4 = reinterpret_cast<float4*>(&s_tile[wv][0][0]);   // (the same bytes, as 16-byte records)
             const int r_lo = leaf.x, r_hi = leaf.x + leaf.y;   // the swept primitives (wave-uniform)
             const int c_first = r_lo >> 6, c_last = (r_hi - 1) >> 6;
             // Lane j's candidate of cluster c: primitive 64 c + j, clamped into the range (idle
@@ -812,6 +833,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                 cmask &= cmask - 1ull;
                 // A round's 64 candidates are fetched one round ahead (vector loads, 16 B/lane,
                 // coalesced) so that their latency hides behind the previous round's survivors.
+                // (Round 3, measured and rejected: two register sets taking turns with the round
+                // body instantiated twice -- no copies, but +11 % on the frame kernel; fetching only
+                // after the round has staged its survivors, into the same registers -- no copies
+                // either, +2.5 %: the loads need the whole round's lead.)
                 float4 mine_next;
                 float2 mineb_next = make_float2(0.f, 0.f);
                 load_cluster(cnext, mine_next, mineb_next);
@@ -852,6 +877,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                         & __builtin_amdgcn_ballot_w64(__builtin_fmaf(sa, da0, noda_hi) < len_lo);
                     lean_round = same_sense & ((rest & ~inside) == 0ull);
                 }
+                bool fat_round = false;
+                if constexpr (LEAN4)
+                    fat_round = (rest & ~__builtin_amdgcn_ballot_w64(mine.w >= fat_r2)) == 0ull;
                 if constexpr (LATTICE && AX >= 0) {
                     // Origin-lattice cull (see the packet set-up): only in rounds over clusters that
                     // hold small spheres, and only if one of them survived the rectangle test.  Kept
@@ -905,7 +933,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                         ? int(__builtin_amdgcn_mbcnt_hi(uint32_t(rest >> 32),
                                                         __builtin_amdgcn_mbcnt_lo(uint32_t(rest), 0u)))
                         : lane;
-                    if (!COMPACT || keep) {
+                    if (LEAN4 && lean_round) {
+                        // test-free round of an axis-aligned packet: all a survivor needs is the two
+                        // perpendicular co-ordinates and the two 1/h terms -- ONE 16-byte record
+                        const float s1 = AX == 0 ? mine.y : mine.x;
+                        const float s2 = AX == 2 ? mine.y : mine.z;
+                        if (keep) tile4[slot] = make_float4(s1, s2, mineb.x, mineb.y);
+                    } else if (!COMPACT || keep) {
                         s_tile[wv][0][slot] = make_float2(mine.x, mine.y);
                         s_tile[wv][LDS_TILE ? 1 : 0][slot] = make_float2(mine.z, mine.w);
                         if (NEED_B) s_tile[wv][LDS_TILE ? 2 : 0][slot] = mineb;
@@ -1014,10 +1048,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                             // +0.  Same bits as the tested path, without the compare, the EXEC
                             // round trip and the branch.
                             const float b = fminf(__builtin_amdgcn_sqrtf(b2) * sb.x, float(N_TABLE - 1));
-                            const int x_idx = static_cast<int>(b);
-                            const float t = __builtin_amdgcn_fractf(b);
-                            const float2 y = s_lutf[x_idx];
-                            sum = __builtin_fmaf(__builtin_fmaf(t, y.y, y.x), sb.y, sum);
+                            const float2 y = s_lutf[static_cast<int>(b)];
+                            sum = __builtin_fmaf(__builtin_fmaf(y.y, b, y.x), sb.y, sum);
                             return;
                         }
                         const bool hit = LEAN ? !(b2 >= s.w)
@@ -1102,8 +1134,56 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
                         if (--left == 0) break;
                     }
                 };
-                if (lean_round) run(std::true_type());
-                else run(std::false_type());
+                // Test-free rounds of axis-aligned packets with the fast integral (every round of an
+                // orthographic projection through the box): survivors as single 16-byte records.
+                // A wave-uniform ds_read_b128 occupies the LDS for 5.5 cycles where the ds_read2_b64
+                // the compiler forms from two 8-byte plane reads takes 9 (measured, scratch
+                // micro-benchmark; MI355X_MICROARCH.md, LDS) -- and the LDS pipe, shared by the CU's
+                // four SIMDs, is what these rounds saturate first.  10 VALU instructions per
+                // survivor: sub sub mul fma | sqrt mul min cvt shl | LDS | fma fma.
+                auto run_lean4 = [&](auto fat_tag) {
+                    // FAT: every survivor's h is at least a third of the packet's origin diagonal, so
+                    // no ray's table position can pass the end of the zero-padded table (some ray
+                    // hits the survivor: any other is within h + diagonal of its centre) -- the
+                    // clamp goes: 10 VALU instructions per survivor.
+                    // (Tried and measured no faster: finishing a survivor one step later, behind the
+                    // next one's table read -- the loop is bound by VALU issue, ~2.7 cycles per
+                    // instruction with the chip's clocks under this load, not by latency.)
+                    constexpr bool FAT = decltype(fat_tag)::value;
+                    float4 c0, c1, c2;
+                    int left = __builtin_popcountll(todo);
+                    const float4* t4 = tile4;
+                    auto proc = [&](const float4 c) {
+                        const float q1 = c.x - o1, q2 = c.y - o2;
+                        float b = __builtin_amdgcn_sqrtf(__builtin_fmaf(q1, q1, q2 * q2)) * c.z;
+                        if (!FAT) b = fminf(b, float(N_TABLE - 1));
+                        const float2 y = s_lutf[static_cast<int>(b)];
+                        sum = __builtin_fmaf(__builtin_fmaf(y.y, b, y.x), c.w, sum);
+                    };
+                    c0 = t4[0]; __builtin_amdgcn_sched_barrier(0);
+                    c1 = t4[1]; __builtin_amdgcn_sched_barrier(0);
+                    for (;;) {
+                        c2 = t4[2]; __builtin_amdgcn_sched_barrier(0);
+                        proc(c0);
+                        if (--left == 0) break;
+                        c0 = t4[3]; __builtin_amdgcn_sched_barrier(0);
+                        proc(c1);
+                        if (--left == 0) break;
+                        c1 = t4[4]; __builtin_amdgcn_sched_barrier(0);
+                        proc(c2);
+                        if (--left == 0) break;
+                        t4 += 3;
+                    }
+                };
+                if constexpr (LEAN4) {
+                    if (lean_round) {
+                        if (fat_round) run_lean4(std::true_type());
+                        else run_lean4(std::false_type());
+                    } else run(std::false_type());
+                } else {
+                    if (lean_round) run(std::true_type());
+                    else run(std::false_type());
+                }
                 STAMP_ADD(st_surv, st_t3);
                 } // !skip_round
                     if (!more) break;

@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
 """Condenses the raw rocprofv3 output of profiles/collect_pmc.sh (gpurun_out/<tag>/) into
-profiles/<out>.json (read by bench.py, keyed by the sha256 of csrc/trace.hip the passes ran on)
+profiles/<out>.json (read by bench.py, keyed by the sha256 of csrc/trace_kernel.hpp the passes ran on)
 and profiles/<out>_kernel_stats.csv (the --stats summary).
 
-    python profiles/make_pmc_json.py gpurun_out/pmc_r2_bench r02_pmc_trace
+    python profiles/make_pmc_json.py gpurun_out/pmc_r3_bench r03_pmc_trace
 """
 import collections, csv, glob, hashlib, json, os, subprocess, sys
 
 src, out = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sha_box = open(os.path.join(src, "trace_hip.sha256")).read().strip()
-sha_here = hashlib.sha256(open(os.path.join(ROOT, "grace-devel_amd", "csrc", "trace.hip"), "rb").read()).hexdigest()
+sha_box = open(os.path.join(src, "trace_kernel.sha256")).read().strip()
+sha_here = hashlib.sha256(open(os.path.join(ROOT, "grace-devel_amd", "csrc", "trace_kernel.hpp"), "rb").read()).hexdigest()
 if sha_box != sha_here:
-    print("WARNING: csrc/trace.hip changed since the passes ran (%s vs %s)" % (sha_box[:12], sha_here[:12]))
+    print("WARNING: csrc/trace_kernel.hpp changed since the passes ran (%s vs %s)" % (sha_box[:12], sha_here[:12]))
 
 
 def short(name):
@@ -55,7 +55,7 @@ doc = {"what": "rocprofv3 PMC passes of `python3 bench.py --steps 5 --warmup 1 -
                "per dispatch averages; recipe profiles/collect_pmc.sh; units: SQ_*CYCLES / SQ_ACTIVE_* / SQ_WAIT_* in "
                "quad-cycles summed over waves or SIMDs, GRBM_GUI_ACTIVE summed over the 8 XCDs, *_SIZE_KB in KiB "
                "(FETCH_SIZE is x2 low on gfx950 for wide loads: corrected by the reader, not here)",
-       "trace_hip_sha256": sha_box, "collected_at_commit": head, "kernels": res}
+       "trace_kernel_sha256": sha_box, "collected_at_commit": head, "kernels": res}
 json.dump(doc, open(os.path.join(ROOT, "profiles", out + ".json"), "w"), indent=1, sort_keys=True)
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     open(os.path.join(ROOT, "profiles", out + "_kernel_stats.csv"), "w").write(open(f).read())
