@@ -448,7 +448,8 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                                                                        hit_chunks, pk_prefix, pk_total);
             GRACE_CHECK_LAUNCH();
             hits_assign_kernel<<<1, 1024, 0, stream>>>(pk_total, n_packets, n_packets * split, hit_chunks,
-                                                       pk_first, pk_parts, n_wave_map);
+                                                       pk_first, pk_parts, n_wave_map,
+                                                       ts.hits_stage_split ? 200000ull : 0ull);
             GRACE_CHECK_LAUNCH();
             hits_bounds_kernel<<<n_packets, 64, 0, stream>>>(pk_prefix, pk_total, pk_first, pk_parts,
                                                              hit_chunks, wave_map);
@@ -457,13 +458,16 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             //    Heavy packets (output-bandwidth-bound: 10^5 isotropic rays through 10^6 large spheres,
             //    410 k hits per packet: 18.0 -> 11.0 ms) stage their hits in LDS and store them eight
             //    per ray at a time; light ones (61 M hits over 768 packets: 3.6 ms direct, 4.5 staged)
-            //    store directly.  The hit total is known on the device only: one 16-byte read-back.
-            unsigned long long h_plan[2] = { 0, 0 };
-            GRACE_TRY_HIP(hipMemcpyAsync(h_plan, n_wave_map, 16, hipMemcpyDeviceToHost, stream));
-            GRACE_TRY_HIP(hipStreamSynchronize(stream));
-            const bool stage = ts.hits_stage_split && h_plan[1] / (unsigned long long)n_packets >= 200000ull;
-            if (stage) both(M_(), T(), T(), a);
-            else both(M_(), T(), F(), a);
+            //    store directly.  The hit total is known on the device only: BOTH variants are
+            //    launched and the plan's flag (hits_assign_kernel) lets one of them run -- no read-back,
+            //    no host synchronisation inside the call.
+            TraceArgs staged = a, direct = a;
+            staged.stage_dev = direct.stage_dev = n_wave_map + 4;
+            staged.stage_want = 1;
+            direct.stage_want = 0;
+            both(M_(), T(), T(), staged);
+            GRACE_CHECK_LAUNCH();
+            both(M_(), T(), F(), direct);
         } else if (n_packets >= 4096) {
             both(M_(), F(), T(), a);
         } else {

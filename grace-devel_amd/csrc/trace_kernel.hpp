@@ -349,6 +349,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     static_assert(!LAT || MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS, "no lattice cull for this mode");
     if (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS) {
         if (a.lat_dev ? (*a.lat_dev != 0) != LAT : LAT) return;   // (workgroup-uniform)
+        if (a.stage_dev && *a.stage_dev != a.stage_want) return;
     }
     constexpr bool FAST = ALT && MODE == MODE_CUMULATIVE;
     __shared__ double2 s_lut[FAST ? 1 : N_TABLE];
@@ -750,9 +751,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
             if (span.y <= treelet) {
                 sweep = true; sweep_first = span.x; sweep_count = span.y;
             } else {
-            // (A wave-uniform box-overlap test of the packet's bounding box -- twelve compares
-            // instead of this per-ray slab test -- was tried twice for axis-aligned packets: same
-            // node count, no gain (node tests are ~320 per packet, ~12 % of the vector work).)
+            // (A wave-uniform box-overlap test of the packet's bounding box instead of this per-ray
+            // slab test was tried three times for axis-aligned packets -- twelve compares with scalar
+            // operands in rounds 1 and 2; in round 3 ONE vector compare, lane j holding dword j of
+            // the node record and its own bound, 2 vector instructions per node instead of ~45: same
+            // node count, no gain each time (2.91 vs 2.92 ms).  The ~100 node tests per packet are a
+            // chain of dependent loads; their vector work is not what the walk waits for.)
             bool hit_l, hit_r;
             aabbs_hit(ix, iy, iz, ox, oy, oz, len, L, R, Z, hit_l, hit_r);
             const unsigned long long vote_r = __builtin_amdgcn_ballot_w64(hit_r);

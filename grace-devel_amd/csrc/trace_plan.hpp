@@ -94,7 +94,8 @@ __global__ __launch_bounds__(1024) void hits_assign_kernel(const uint32_t* __res
                                                            int n_packets, int n_waves, int n_chunks,
                                                            int* __restrict__ pk_first,
                                                            int* __restrict__ pk_parts,
-                                                           int* __restrict__ n_used)
+                                                           int* __restrict__ n_used,
+                                                           const unsigned long long stage_min_per_packet)
 {
     __shared__ unsigned long long s_red[16];
     __shared__ int s_scan[16];
@@ -131,7 +132,9 @@ __global__ __launch_bounds__(1024) void hits_assign_kernel(const uint32_t* __res
     }
     if (threadIdx.x == 0) {
         *n_used = s_carry;
-        *reinterpret_cast<unsigned long long*>(n_used + 2) = H;   // the batch's hit total, for the host
+        *reinterpret_cast<unsigned long long*>(n_used + 2) = H;   // the batch's hit total
+        // n_used[4]: the per-hit walk's variant -- heavy packets stage their hits in LDS
+        n_used[4] = (stage_min_per_packet != 0ull && H / (unsigned long long)n_packets >= stage_min_per_packet) ? 1 : 0;
     }
 }
 

@@ -46,6 +46,10 @@ struct TraceArgs {
     // split, chosen on the device from the batch's coherence); waves beyond it exit at once.
     const int* split_dev;
     const int* lat_dev;     // which of the LAT = false / true instantiations runs (null: false)
+    // Split per-hit walk: which of the direct (0) / LDS-staged (1) instantiations runs -- both are
+    // launched, the device-side plan (hits_assign_kernel) has set *stage_dev (null: no gate).
+    const int* stage_dev;
+    int stage_want;
     // Split per-hit trace (small batches): primitives are cut into n_chunks ranges of
     // 2^chunk_shift consecutive indices.  The counting pass fills chunk_counts[ray][chunk];
     // the per-hit pass lets wave w own chunks [wave_map[w].y, wave_map[w].z) of packet
