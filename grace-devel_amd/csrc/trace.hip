@@ -180,19 +180,22 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     // 2-4x the waves, each with a tighter beam, on a chip that would otherwise sit idle.
     int width = 64;
     if (ts.width > 0) width = ts.width;
-    else if ((MODE == MODE_HITS && !hits_split) || MODE == MODE_TRI || MODE == MODE_COUNT_D4
-             || MODE == MODE_CUM_D4 || MODE == MODE_HITS_D4)
+    else if ((MODE == MODE_HITS && !hits_split) || MODE == MODE_TRI || MODE == MODE_HITS_D4)
         while (width > 16 && ceil_div(n_rays, size_t(width)) < 4096) width /= 2;
     // Hit counts and column densities split packets eight ways at most; a batch too small to fill
     // the chip even then (< 512 packets) also gets narrower packets (10^7 particles, 12288 HEALPix
     // rays: 3.5 -> 2.0 ms at 16 rays per packet; from 49152 rays on it loses: config 3 0.87 -> 0.95 ms).
-    else if ((MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) && ts.split <= 0)
+    else if ((MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_COUNT_D4 || MODE == MODE_CUM_D4)
+             && ts.split <= 0)
         while (width > 16 && ceil_div(n_rays, size_t(width)) * SUM_CLASSES < 4096) width /= 2;
     a.width = width;
     const int n_packets = ceil_div(n_rays, size_t(width));
     // Waves per packet: two resident sets of waves (2 x 8192) for small ray batches.
     int split = 1;
-    if (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) {
+    // (double4 hit counts and column densities split the same way: the same classes, summed in double)
+    constexpr bool CLASS_SPLIT = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_COUNT_D4
+                                  || MODE == MODE_CUM_D4);
+    if (CLASS_SPLIT) {
         if (ts.split > 0) split = ts.split;
         else while (split < SUM_CLASSES && size_t(n_packets) * split < 16384) split *= 2;
     }
@@ -249,6 +252,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                                                    + 4 * Workspace::aligned(hit_packets * 4 + 64)
                                                    + Workspace::aligned(n_rays * 4) : 0)
                                    + (MODE == MODE_CUMULATIVE ? Workspace::aligned(n_rays * SUM_CLASSES * 4) : 0)
+                                   + (MODE == MODE_CUM_D4 ? Workspace::aligned(n_rays * SUM_CLASSES * 8) : 0)
                                    + (reorder ? 2 * Workspace::aligned(n_rays * 4)
                                                 + sort_ws_bytes(n_rays, 4, 0) : 0)
                                    + (any_sig ? Workspace::aligned(sig_partial_words() * 8) : 0) + 1024, stream));
@@ -291,6 +295,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             a.A = A; a.B = B; a.T64 = T64; a.node_prims = node_prims; a.C = C;
         }
         a.partial = (MODE == MODE_CUMULATIVE) ? Workspace::take<float>(n_rays * SUM_CLASSES) : nullptr;
+        a.partial_d = (MODE == MODE_CUM_D4) ? Workspace::take<double>(n_rays * SUM_CLASSES) : nullptr;
         if (hits_split) {
             chunk_counts = Workspace::take<int>(n_rays * size_t(hit_chunks));
             chunk_off = Workspace::take<int>(n_rays * size_t(hit_chunks));
@@ -360,7 +365,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     a.chunk_off = chunk_off;
     a.wave_map = wave_map;
     a.n_wave_map = n_wave_map;
-    if (split > 1 && MODE == MODE_COUNT)
+    if (split > 1 && (MODE == MODE_COUNT || MODE == MODE_COUNT_D4))
         GRACE_TRY_HIP(hipMemsetAsync(a.out_counts, 0, n_rays * sizeof(int), stream));
     if (keep_chunks && split > 1) {
         a.chunk_counts = ts.hits.chunk_counts;
@@ -408,7 +413,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         trace_kernel<M, true, A, true><<<ceil_div(size_t(n_packets) * ts.lat_split, TRACE_BLOCK / 64), TRACE_BLOCK, 0, stream>>>(a8);
         GRACE_CHECK_LAUNCH();
         if (MODE == MODE_CUMULATIVE) {
-            combine_classes_kernel<<<ceil_div(n_rays, 256), 256, 0, stream>>>(a.partial, int(n_rays), ts.lat_split,
+            combine_classes_kernel<float><<<ceil_div(n_rays, 256), 256, 0, stream>>>(a.partial, int(n_rays), ts.lat_split,
                                                                               nullptr, a.out_sums, a.lat_dev);
             GRACE_CHECK_LAUNCH();
         }
@@ -477,14 +482,22 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         if (split > 1) both(M_(), T(), F(), a);
         else if (lat_split) GRACE_TRY(one_or_split(F()));
         else both(M_(), F(), F(), a);
+    } else if constexpr (MODE == MODE_COUNT_D4 || MODE == MODE_CUM_D4) {
+        if (split > 1) trace_kernel<MODE, true><<<grid, TRACE_BLOCK, 0, stream>>>(a);
+        else trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
     } else {
         trace_kernel<MODE, false><<<grid, TRACE_BLOCK, 0, stream>>>(a);
     }
     GRACE_CHECK_LAUNCH();
     GRACE_TRY(stamps_report(MODE));
+    if (MODE == MODE_CUM_D4 && split > 1) {
+        combine_classes_kernel<double><<<ceil_div(n_rays, 256), 256, 0, stream>>>(a.partial_d, int(n_rays), split,
+                                                                                   nullptr, a.out_sums_d);
+        GRACE_CHECK_LAUNCH();
+    }
     if (MODE == MODE_CUMULATIVE && split > 1) {
-        combine_classes_kernel<<<ceil_div(n_rays, 256), 256, 0, stream>>>(a.partial, int(n_rays),
-                                                                          split, a.split_dev, a.out_sums);
+        combine_classes_kernel<float><<<ceil_div(n_rays, 256), 256, 0, stream>>>(a.partial, int(n_rays),
+                                                                                 split, a.split_dev, a.out_sums);
         GRACE_CHECK_LAUNCH();
     }
     if (ts.timing) {

@@ -343,7 +343,8 @@ __device__ __forceinline__ bool cluster_may_hit(const float4 blo, const float4 b
 // class-split kernels registers they do not have, and the frame kernel 2 %, so scenes without
 // sub-spacing spheres must not carry it.
 template <int MODE, bool SPLIT, bool ALT = false, bool LAT = false>
-__global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) void trace_kernel(const TraceArgs a)
+__global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE)) ? 8 : 1)
+void trace_kernel(const TraceArgs a)
 {
     static_assert(!ALT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS, "no alternative path for this mode");
     static_assert(!LAT || MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS, "no lattice cull for this mode");
@@ -371,7 +372,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     // (the division is done once per candidate by its lane, not once per survivor by the wave).
     __shared__ double s_tile_d[D4 ? TRACE_BLOCK / 64 : 1][D4 ? 64 : 1][D4 ? 6 : 1];
     const int lane = threadIdx.x & 63;
-    constexpr bool SPLITTABLE = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
+    constexpr bool SPLITTABLE = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS
+                                 || MODE == MODE_COUNT_D4 || MODE == MODE_CUM_D4);
     static_assert(!SPLIT || SPLITTABLE, "triangle and stats walks do not split");
     // Hit counts and column densities split a packet by summation class (interleaved granules);
     // the per-hit trace, whose output is ordered, by contiguous chunk ranges chosen per packet.
@@ -606,22 +608,34 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     int count_at_chunk = 0;
     float sum = 0.f;        // accumulator of the current granule's class (MODE_CUMULATIVE)
     // Class accumulators of this wave's lanes (one wave = one row of the workgroup's array).
-    constexpr bool CLASSES = (MODE == MODE_CUMULATIVE);
-    __shared__ float s_class[CLASSES ? TRACE_BLOCK / 64 : 1][CLASSES ? SUM_CLASSES : 1][CLASSES ? 64 : 1];
+    // (MODE_CUM_D4: the same classes, accumulated and combined in double)
+    constexpr bool CLASSES_F = (MODE == MODE_CUMULATIVE), CLASSES_D = (MODE == MODE_CUM_D4);
+    constexpr bool CLASSES = CLASSES_F || CLASSES_D;
+    __shared__ float s_class[CLASSES_F ? TRACE_BLOCK / 64 : 1][CLASSES_F ? SUM_CLASSES : 1][CLASSES_F ? 64 : 1];
+    __shared__ double s_class_d[CLASSES_D ? TRACE_BLOCK / 64 : 1][CLASSES_D ? SUM_CLASSES : 1][CLASSES_D ? 64 : 1];
     const int wv_acc = threadIdx.x >> 6;
-    if (CLASSES) {
+    if (CLASSES_F) {
 #pragma unroll
         for (int c = 0; c < SUM_CLASSES; ++c) s_class[wv_acc][c][lane] = 0.f;
     }
+    if (CLASSES_D) {
+#pragma unroll
+        for (int c = 0; c < SUM_CLASSES; ++c) s_class_d[wv_acc][c][lane] = 0.0;
+    }
+    double sum_d = 0.0;     // MODE_CUM_D4: accumulator of the current granule's class
     int cur_granule = -1;            // wave-uniform
     int cur_granule_end = 0;         // first primitive past the current granule
     bool cur_owned = true;
     auto enter_granule = [&](const int prim) {
-        if (cur_granule >= 0) s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane] = sum;
+        if (cur_granule >= 0) {
+            if (CLASSES_D) s_class_d[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane] = sum_d;
+            else s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane] = sum;
+        }
         cur_granule = prim >> GRANULE_SHIFT;
         cur_granule_end = (cur_granule + 1) << GRANULE_SHIFT;
         cur_owned = !SPLIT || owns_granule(cur_granule);
-        sum = s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane];
+        if (CLASSES_D) sum_d = s_class_d[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane];
+        else sum = s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane];
     };
     int write_at = 0;
     auto leave_chunk = [&]() {
@@ -635,7 +649,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
     float tri_tmin = len * (1.f + 0.000001f);
     const double ddx = dx, ddy = dy, ddz = dz;
     if (MODE == MODE_HITS || MODE == MODE_HITS_D4) write_at = a.offsets[ray_index];
-    double sum_d = 0.0;     // MODE_CUM_D4: one running double sum per ray, ascending primitive index
     const double rdx = dx, rdy = dy, rdz = dz;
     // MODE_HITS: every ray owns a contiguous output segment, so lanes writing hit by hit
     // touch 64 different cache lines per store and the partial lines thrash L2 (measured:
@@ -1231,8 +1244,23 @@ __global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && MODE != MODE_HITS) ? 8 : 1) 
         else if (count) atomicAdd(&a.out_counts[ray_index], count); // output zeroed by the host
     }
     if (MODE == MODE_TRI) a.out_counts[ray_index] = tri_data;
-    if (MODE == MODE_COUNT_D4) a.out_counts[ray_index] = count;
-    if (MODE == MODE_CUM_D4) a.out_sums_d[ray_index] = sum_d;
+    if (MODE == MODE_COUNT_D4) {
+        if (!SPLIT) a.out_counts[ray_index] = count;
+        else if (count) atomicAdd(&a.out_counts[ray_index], count); // output zeroed by the host
+    }
+    if (MODE == MODE_CUM_D4) {
+        // the float path's class-ordered sum, in double: pairwise over the 8 classes (this wave's
+        // subtree of it when the packet is split)
+        if (cur_granule >= 0) s_class_d[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane] = sum_d;
+        const int c_lo = SPLIT ? own_lo : 0, c_n = SPLIT ? classes_per_part : SUM_CLASSES;
+        for (int w = 1; w < c_n; w *= 2)
+            for (int c = c_lo; c < c_lo + c_n; c += 2 * w) {
+                const double x = s_class_d[wv_acc][c][lane], y = s_class_d[wv_acc][c + w][lane];
+                s_class_d[wv_acc][c][lane] = x + y;
+            }
+        if (!SPLIT) a.out_sums_d[ray_index] = s_class_d[wv_acc][0][lane];
+        else a.partial_d[size_t(ray_index) * split + part] = s_class_d[wv_acc][c_lo][lane];
+    }
     if (MODE == MODE_CUMULATIVE) {
         if (cur_granule >= 0) s_class[wv_acc][cur_granule & (SUM_CLASSES - 1)][lane] = sum;
         // Pairwise sum of this wave's classes (a subtree of the summation tree).

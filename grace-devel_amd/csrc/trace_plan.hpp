@@ -9,17 +9,18 @@ namespace {
 using namespace grace_hip;
 
 // Upper levels of the pairwise summation tree for split packets: K subtree sums per ray.
-__global__ __launch_bounds__(256) void combine_classes_kernel(const float* __restrict__ partial,
+template <typename Real>
+__global__ __launch_bounds__(256) void combine_classes_kernel(const Real* __restrict__ partial,
                                                               int n_rays, int split,
                                                               const int* __restrict__ split_dev,
-                                                              float* __restrict__ out,
+                                                              Real* __restrict__ out,
                                                               const int* __restrict__ run_if = nullptr)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
     if (run_if && *run_if == 0) return;   // the one-wave-per-packet kernel ran: `out` is final
     if (split_dev) split = *split_dev;
-    float t[SUM_CLASSES];
+    Real t[SUM_CLASSES];
     for (int k = 0; k < split; ++k) t[k] = partial[size_t(r) * split + k];
     for (int w = 1; w < split; w *= 2)
         for (int k = 0; k < split; k += 2 * w) t[k] = t[k] + t[k + w];

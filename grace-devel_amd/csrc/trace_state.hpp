@@ -42,6 +42,7 @@ struct TraceArgs {
     int split;              // waves per packet (1, 2, 4, 8); each owns SUM_CLASSES / split classes
     int n_prims;
     float* partial;         // split > 1, cumulative: [n_rays][split] subtree sums
+    double* partial_d;      // ... of the double4 trace
     // Class split only: the number of waves per packet that actually work (a power of two <=
     // split, chosen on the device from the batch's coherence); waves beyond it exit at once.
     const int* split_dev;

@@ -1096,16 +1096,27 @@ void go_brute_hitcounts_d4(const go_ray* rays, size_t n_rays, const double* s, s
     }
 }
 
-/* One running double sum per ray in ascending primitive index (RayData_sphere<double,double>). */
-void go_brute_cumulative_d4(const go_ray* rays, size_t n_rays, const double* s, size_t n, double* out)
+/* Column densities of double4 spheres.  The reference keeps one running double sum per ray in
+ * ascending primitive index (RayData_sphere<double,double>); blocks = 1 gives that.  This
+ * implementation's stated result (blocks > 1) is the float path's CLASS-ORDERED sum in double: class
+ * (p >> 10) & 7, each class summed in ascending primitive order, the 8 class sums added pairwise --
+ * so that a packet of double4 rays can be shared by up to 8 waves, like a float one.  The two
+ * differ by a few ulp of double (1e-16 relative); the stated tolerance is 1e-5. */
+void go_brute_cumulative_d4(const go_ray* rays, size_t n_rays, const double* s, size_t n, double* out, int blocks)
 {
     #pragma omp parallel for schedule(dynamic, 16)
     for (size_t ri = 0; ri < n_rays; ++ri) {
         go_ray ray = rays[ri];
-        double acc = 0.0, b2, d;
+        double cls[GO_SUM_CLASSES], b2, d;
+        for (int c = 0; c < GO_SUM_CLASSES; ++c) cls[c] = 0.0;
         for (size_t si = 0; si < n; ++si)
-            if (sphere_hit_d(&ray, s + 4 * si, &b2, &d)) acc += hit_integral_d(b2, s[4 * si + 3]);
-        out[ri] = acc;
+            if (sphere_hit_d(&ray, s + 4 * si, &b2, &d)) {
+                const int c = blocks > 1 ? (int)((si >> GO_GRANULE_SHIFT) & (GO_SUM_CLASSES - 1)) : 0;
+                cls[c] += hit_integral_d(b2, s[4 * si + 3]);
+            }
+        for (int w = 1; w < GO_SUM_CLASSES; w *= 2)
+            for (int c = 0; c < GO_SUM_CLASSES; c += 2 * w) cls[c] = cls[c] + cls[c + w];
+        out[ri] = cls[0];
     }
 }
 

@@ -369,9 +369,12 @@ def brute_hitcounts_d4(rays, prims):
     return out
 
 
-def brute_cumulative_d4(rays, prims):
+def brute_cumulative_d4(rays, prims, blocks=SUM_BLOCKS):
+    """blocks > 1 (default): the class-ordered double sum (this implementation's stated result);
+    blocks = 1: the reference's single running double sum."""
     rays = _rays(rays); prims = np.ascontiguousarray(prims, np.float64)
     out = np.empty(len(rays), np.float64)
-    lib().go_brute_cumulative_d4(_p(rays), C.c_size_t(len(rays)), _p(prims), C.c_size_t(len(prims)), _p(out))
+    lib().go_brute_cumulative_d4(_p(rays), C.c_size_t(len(rays)), _p(prims), C.c_size_t(len(prims)), _p(out),
+                                 C.c_int(blocks))
     return out
 

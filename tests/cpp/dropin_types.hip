@@ -105,15 +105,16 @@ int main(int argc, char* argv[])
         int before = failures;
         size_t at = 0;
         for (size_t r = 0; r < N_rays; ++r) {
-            int hits = 0; double b2, d, sum = 0.0;
+            int hits = 0; double b2, d, cls[8] = { 0., 0., 0., 0., 0., 0., 0., 0. };
             if (h_offsets[r] != (int)at) ++failures;
             for (size_t s = 0; s < N; ++s)
                 if (grace::sphere_hit(h_rays[r], h_spheres[s], b2, d)) {
                     const double w = integral_d(b2, h_spheres[s].w);
-                    sum += w;
+                    cls[(s >> 10) & 7] += w;      // the library's summation order: 8 interleaved classes
                     if (at < h_idx.size() && (h_idx[at] != (int)s || h_int[at] != w || h_dist[at] != d)) ++failures;
                     ++at; ++hits;
                 }
+            const double sum = ((cls[0] + cls[1]) + (cls[2] + cls[3])) + ((cls[4] + cls[5]) + (cls[6] + cls[7]));
             if (hits != h_counts[r] || sum != h_cum[r]) ++failures;
         }
         if (at != h_idx.size()) ++failures;

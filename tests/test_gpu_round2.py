@@ -404,15 +404,17 @@ def test_double4_area_deltas_per_hit_trace_and_distance_sort(gh, oracle, cuda):
     cu = torch.empty(n_rays, dtype=torch.float64, device=cuda)
     gh.trace_cumulative_d4(rays, d, tree, cu)
     assert np.array_equal(cu.cpu().numpy(), oracle.brute_cumulative_d4(rr, ss))
-    # per ray: indices ascending; the running double sum of the per-hit integrals in hit order
-    # IS the ray's column density (same doubles, same order)
+    # per ray: indices ascending; the class-ordered double sum of the per-hit integrals (class =
+    # (index >> 10) & 7, each class in hit order, the 8 class sums added pairwise) IS the ray's
+    # column density (same doubles, same order)
     o = np.append(offs.cpu().numpy(), len(idx)); ih = idx.cpu().numpy(); wh = w.cpu().numpy(); dh = dist.cpu().numpy()
     for r in range(0, n_rays, 37):
         seg = slice(o[r], o[r + 1])
         assert np.all(np.diff(ih[seg]) > 0)
-        acc = 0.0
-        for x in wh[seg]:
-            acc += x
+        cls = [0.0] * 8
+        for i, x in zip(ih[seg], wh[seg]):
+            cls[(int(i) >> 10) & 7] += float(x)
+        acc = ((cls[0] + cls[1]) + (cls[2] + cls[3])) + ((cls[4] + cls[5]) + (cls[6] + cls[7]))
         assert acc == cu.cpu().numpy()[r]
         assert np.all((dh[seg] >= 0) & (dh[seg] < 2.0))
     # sort_by_distance<double>: == stable per-segment sort
