@@ -343,7 +343,11 @@ __device__ __forceinline__ bool cluster_may_hit(const float4 blo, const float4 b
 // class-split kernels registers they do not have, and the frame kernel 2 %, so scenes without
 // sub-spacing spheres must not carry it.
 template <int MODE, bool SPLIT, bool ALT = false, bool LAT = false>
-__global__ __launch_bounds__(TRACE_BLOCK, (SPLIT && (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE)) ? 8 : 1)
+// The one-wave-per-packet hit-count / column-density kernels are held to 6 waves per SIMD (<= 80
+// VGPRs): left to itself the register allocator drifts between 77 and 102 VGPRs from one edit of
+// this file to the next, and at 5 waves per SIMD the frame kernel loses 20 % (2.9 -> 3.55 ms,
+// measured when an unrelated change tipped it over).
+__global__ __launch_bounds__(TRACE_BLOCK, (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE) ? (SPLIT ? 8 : 6) : 1)
 void trace_kernel(const TraceArgs a)
 {
     static_assert(!ALT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS, "no alternative path for this mode");
