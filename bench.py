@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0            # HBM3E spec
 N_SIMDS = 256 * 4
 MAX_CLOCK_GHZ = 2.4
 VALU_PEAK_GINST = N_SIMDS * MAX_CLOCK_GHZ / 2.0   # v_fma_f32 wave64: 2 cycles per SIMD-32
-MIN_VALU_PER_HIT = 12   # sub sub mul fma | sqrt mul min cvt fract shl | fma fma (csrc/trace.hip, lean fast round)
+MIN_VALU_PER_HIT = 10   # sub sub mul fma | sqrt mul cvt shl | LDS | fma fma (csrc/trace_kernel.hpp, test-free rounds of fat spheres)
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_trace.json")
 TRACE_SRC = os.path.join(ROOT, "grace-devel_amd", "csrc", "trace_kernel.hpp")   # the kernel's source
 

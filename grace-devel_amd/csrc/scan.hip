@@ -115,11 +115,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_slab_kernel(const uint32_t* i
     if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = carry;
 }
 
-// Small inputs (the radix sort's digit tables of up to 2^18 counters -- the ray-order sort's 65536
+// Small inputs (digit tables of up to 2^16 counters -- the ray-order sort of 10^6 rays has 65536
 // -- and the like): ONE workgroup of 1024 threads, each thread owning a contiguous run, instead of
 // reduce / scan-of-sums / scan launches of a few microseconds each.
 constexpr int SCAN_SMALL_BLOCK = 1024;
-constexpr size_t SCAN_SMALL_MAX = size_t(1) << 18;
+constexpr size_t SCAN_SMALL_MAX = size_t(1) << 16;   // (one workgroup streams ~50 GB/s: beyond this the three launches win)
 
 __global__ __launch_bounds__(SCAN_SMALL_BLOCK) void scan_small_kernel(const uint32_t* in, uint32_t* out,
                                                                       size_t n,

@@ -841,6 +841,12 @@ grace_status grace_trace_set_cache_auto(int enabled)
 {
     GRACE_TRACE_STATE();
     ts.cache_auto = enabled != 0;
+    if (!ts.cache_auto) {     // what was cached automatically goes; pinned (prepared) records stay
+        if (ts.scene.valid && !ts.scene.pinned) GRACE_TRY(scene_release(ts));
+        if (ts.rays.valid && !ts.rays.pinned) GRACE_TRY(rays_release(ts));
+        ts.scene.seen = SceneKey();
+        ts.rays.seen = RayKey();
+    }
     return GRACE_OK;
 }
 
