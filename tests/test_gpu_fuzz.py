@@ -1,8 +1,9 @@
 """Randomised differential test: random scenes, ray generators, packet orders, split factors,
 packet widths, treelet sizes and integral modes; hit counts, column densities and per-hit
-outputs against the oracle's brute force on a subset of the rays.  (The same loop ran 3192
-configurations in round 1 and 4743 in round 2 -- profiles/recipes/fuzz_trace.py, seven minutes on
-MI355X -- without a failure; 60 fixed seeds are kept here.)"""
+outputs against the oracle's brute force on a subset of the rays; from round 3 on also the cached
+paths (the same call three times: uncached, filling the cache, validated cache).  (The same loop
+ran 3192 configurations in round 1, 4743 in round 2 and 3296 in round 3 --
+profiles/recipes/fuzz_trace.py on MI355X -- without a failure; 60 fixed seeds are kept here.)"""
 import math
 
 import numpy as np
@@ -63,7 +64,12 @@ def _one(gh, O, dev, rng, seed):
     hc=torch.empty(R,dtype=torch.int32,device=dev); cu=torch.empty(R,dtype=torch.float32,device=dev)
     gh.trace_hitcounts_sph(rays,d,tree,hc); gh.trace_cumulative_sph(rays,d,tree,cu)
     offs,idx,w,dist=gh.trace_sph(rays,d,tree)
+    # the same call twice more: the second derives its records into the library's cache, the third
+    # runs on cached records validated by signature (round 3) -- the same bits every time
+    cu2=torch.empty_like(cu); cu3=torch.empty_like(cu)
+    gh.trace_cumulative_sph(rays,d,tree,cu2); gh.trace_cumulative_sph(rays,d,tree,cu3)
     gh.trace_status()
+    assert torch.equal(cu,cu2) and torch.equal(cu,cu3), dict(n=n, kind=str(kind), R=R, cached="differs")
     sub=np.unique(rng.integers(0,R,min(R,160)))
     rr=rays.cpu().numpy()
     ref_c=O.brute_hitcounts(rr[sub],ss); c32,c64=O.brute_cumulative(rr[sub],ss)
