@@ -115,38 +115,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_slab_kernel(const uint32_t* i
     if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = carry;
 }
 
-// Small inputs (digit tables of up to 2^16 counters -- the ray-order sort of 10^6 rays has 65536
-// -- and the like): ONE workgroup of 1024 threads, each thread owning a contiguous run, instead of
-// reduce / scan-of-sums / scan launches of a few microseconds each.
-constexpr int SCAN_SMALL_BLOCK = 1024;
-constexpr size_t SCAN_SMALL_MAX = size_t(1) << 16;   // (one workgroup streams ~50 GB/s: beyond this the three launches win)
-
-__global__ __launch_bounds__(SCAN_SMALL_BLOCK) void scan_small_kernel(const uint32_t* in, uint32_t* out,
-                                                                      size_t n,
-                                                                      uint32_t* __restrict__ total_out,
-                                                                      const uint32_t* __restrict__ run_if)
-{
-    if (run_if && *run_if == 0u) return;
-    __shared__ uint32_t s_wave[SCAN_SMALL_BLOCK / 64];
-    const size_t per = (n + SCAN_SMALL_BLOCK - 1) / SCAN_SMALL_BLOCK;
-    const size_t lo = min(size_t(threadIdx.x) * per, n), hi = min(lo + per, n);
-    uint32_t sum = 0;
-    for (size_t i = lo; i < hi; ++i) sum += in[i];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t incl = wave_inclusive_sum(sum, lane);
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-    for (int w = 0; w < SCAN_SMALL_BLOCK / 64; ++w) {
-        const uint32_t t = s_wave[w];
-        if (w < wave) base += t;
-        tot += t;
-    }
-    uint32_t run = base + incl - sum;
-    for (size_t i = lo; i < hi; ++i) { const uint32_t v = in[i]; out[i] = run; run += v; }
-    if (total_out && threadIdx.x == 0) *total_out = tot;
-}
-
 } // namespace
 
 namespace grace_hip {
@@ -170,11 +138,9 @@ grace_status exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, size_t n,
         return GRACE_OK;
     }
     const size_t n_slabs = (n + SCAN_SLAB - 1) / SCAN_SLAB;
-    if (n_slabs > 1 && n <= SCAN_SMALL_MAX) {
-        scan_small_kernel<<<1, SCAN_SMALL_BLOCK, 0, stream>>>(d_in, d_out, n, d_total, run_if);
-        GRACE_CHECK_LAUNCH();
-        return GRACE_OK;
-    }
+    // (A single-workgroup kernel for tables of a few slabs -- the ray-order sort's 65536 counters --
+    // was tried in round 3 to save two launches: one workgroup streams the table at ~1.5 GB/s,
+    // 97 us against the 12 us of the three launches below.)
     if (n_slabs == 1) {
         scan_slab_kernel<<<1, SCAN_BLOCK, 0, stream>>>(d_in, d_out, n, nullptr, d_total, run_if);
         GRACE_CHECK_LAUNCH();
