@@ -66,9 +66,18 @@ struct Context {
     // ALBVH phase timing (grace_albvh_enable_timing)
     bool phase_timing = false, phase_valid = false;
     hipEvent_t phase_events[3] = { nullptr, nullptr, nullptr };
+    // a second stream for launches that are off the critical path (the sort's gated fallback):
+    // forked from and joined to the call's stream by events, see side_fork / side_join
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork_ev = nullptr, side_join_ev = nullptr;
     // traversal state, owned by the trace translation units
     TraceState* trace = nullptr;
 };
+
+// The frame context's side stream, ordered after everything enqueued on `stream` so far ...
+grace_status side_fork(hipStream_t stream, hipStream_t* side);
+// ... and `stream` ordered after everything enqueued on the side stream so far.
+grace_status side_join(hipStream_t stream);
 
 // The calling thread's context: the one it made current, else the current device's default
 // context.  Fails if the thread's explicit context belongs to another device than the current one.

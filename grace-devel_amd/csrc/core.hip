@@ -73,6 +73,45 @@ static grace_status context_clear(Context& c)
         e = nullptr;
     }
     c.phase_valid = false;
+    if (c.side_stream) {
+        GRACE_TRY_HIP(hipStreamSynchronize(c.side_stream));
+        GRACE_TRY_HIP(hipStreamDestroy(c.side_stream));
+        GRACE_TRY_HIP(hipEventDestroy(c.side_fork_ev));
+        GRACE_TRY_HIP(hipEventDestroy(c.side_join_ev));
+    }
+    c.side_stream = nullptr;
+    c.side_fork_ev = c.side_join_ev = nullptr;
+    return GRACE_OK;
+}
+
+grace_status side_fork(hipStream_t stream, hipStream_t* side)
+{
+    Context* c = Workspace::frame_context();
+    GRACE_REQUIRE(c && c->ws_frame_open, "side_fork: no open frame");
+    if (!c->side_stream) {
+        hipStream_t s = nullptr;
+        GRACE_TRY_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+            if (a) (void)hipEventDestroy(a);
+            (void)hipStreamDestroy(s);
+            return set_error(GRACE_HIP_ERROR, __FILE__, __LINE__, "side_fork: event creation failed");
+        }
+        c->side_stream = s; c->side_fork_ev = a; c->side_join_ev = b;
+    }
+    GRACE_TRY_HIP(hipEventRecord(c->side_fork_ev, stream));
+    GRACE_TRY_HIP(hipStreamWaitEvent(c->side_stream, c->side_fork_ev, 0));
+    *side = c->side_stream;
+    return GRACE_OK;
+}
+
+grace_status side_join(hipStream_t stream)
+{
+    Context* c = Workspace::frame_context();
+    GRACE_REQUIRE(c && c->side_stream, "side_join: no side stream");
+    GRACE_TRY_HIP(hipEventRecord(c->side_join_ev, c->side_stream));
+    GRACE_TRY_HIP(hipStreamWaitEvent(stream, c->side_join_ev, 0));
     return GRACE_OK;
 }
 

@@ -375,3 +375,91 @@ def test_trusted_mode_and_pinned_caches(gh, oracle, cuda):
             assert torch.equal(o, want)
     finally:
         gh.set_cache_auto(True)
+
+
+# ---- bucket sort (inputs >= 2^17 elements): one MSD pass with the payload + per-bucket LDS sort;
+# ---- a bucket beyond a workgroup's capacity turns on the gated index sort instead (csrc/sort.hip)
+
+def _check_sort(gh, cuda, keys, vals, begin, end, want_perm=True):
+    kd = torch.from_numpy(keys.view(np.int32 if keys.dtype == np.uint32 else np.int64)).to(cuda)
+    vd = torch.from_numpy(vals).to(cuda) if vals is not None else None
+    perm = gh.sort_by_key(kd, vd, begin, end, want_perm=want_perm)
+    width = np.uint64(end - begin)
+    digit = (keys.astype(np.uint64) >> np.uint64(begin)) & ((np.uint64(1) << width) - np.uint64(1))
+    order = np.argsort(digit, kind="stable")
+    assert np.array_equal(kd.cpu().numpy().view(keys.dtype), keys[order])
+    if vals is not None:
+        assert np.array_equal(vd.cpu().numpy(), vals[order])
+    if want_perm:
+        assert np.array_equal(perm.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+
+
+@pytest.mark.parametrize("words", [0, 1, 2, 3, 4, 7, 8])
+@pytest.mark.parametrize("n", [262144, 262145, 300001, 1 << 20])
+def test_bucket_sort_uniform_keys(gh, cuda, n, words):
+    rng = np.random.default_rng(n + words)
+    keys = rng.integers(0, 1 << 30, n, dtype=np.uint32)
+    keys[: n // 50] &= 0x3FF00000          # duplicates inside buckets: stability matters
+    vals = rng.integers(0, 1 << 31, (n, words), dtype=np.int32) if words else None
+    _check_sort(gh, cuda, keys, vals, 0, 30, want_perm=(words in (0, 4)))
+
+
+@pytest.mark.parametrize("case", ["one_value", "few_values", "half_in_one_bucket", "sorted", "reversed"])
+def test_bucket_sort_overflowing_buckets(gh, cuda, case):
+    n = 700001
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 1 << 30, n, dtype=np.uint32)
+    if case == "one_value":
+        keys[:] = 0x2AAAAAAA
+    elif case == "few_values":
+        keys = rng.integers(0, 37, n, dtype=np.uint32) << np.uint32(13)
+    elif case == "half_in_one_bucket":
+        keys[: n // 2] = (keys[: n // 2] & np.uint32(0x3FFFF)) | np.uint32(0x155 << 18)
+    elif case == "sorted":
+        keys = np.sort(keys)
+    elif case == "reversed":
+        keys = np.sort(keys)[::-1].copy()
+    vals = rng.integers(0, 1 << 31, (n, 4), dtype=np.int32)
+    _check_sort(gh, cuda, keys, vals, 0, 30)
+    # a second, uniform call right after (same workspace, flags recomputed)
+    keys2 = rng.integers(0, 1 << 30, n, dtype=np.uint32)
+    _check_sort(gh, cuda, keys2, vals, 0, 30)
+
+
+@pytest.mark.parametrize("begin,end", [(0, 32), (3, 27), (10, 30), (0, 17), (12, 20), (0, 8)])
+def test_bucket_sort_bit_ranges(gh, cuda, begin, end):
+    n = 400003
+    rng = np.random.default_rng(begin * 100 + end)
+    keys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    vals = rng.integers(0, 1 << 31, (n, 2), dtype=np.int32)
+    _check_sort(gh, cuda, keys, vals, begin, end)
+
+
+@pytest.mark.parametrize("begin,end", [(0, 63), (0, 30), (20, 52), (40, 64)])
+def test_bucket_sort_u64(gh, cuda, begin, end):
+    n = 300007
+    rng = np.random.default_rng(end)
+    keys = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    if end == 64:
+        keys |= rng.integers(0, 2, n, dtype=np.uint64) << np.uint64(63)
+    keys[::11] = keys[5]
+    vals = rng.integers(0, 1 << 31, (n, 4), dtype=np.int32)
+    _check_sort(gh, cuda, keys, vals, begin, end)
+
+
+def test_bucket_sort_full_size_properties(gh, cuda):
+    """10^7 keys (BASELINE config 4's build): sortedness, stability through the carried index,
+    payload follows its key."""
+    n = 10_000_000
+    g = torch.Generator(device=cuda); g.manual_seed(3)
+    keys = torch.randint(0, 1 << 30, (n,), dtype=torch.int32, device=cuda, generator=g)
+    keys[: n // 4] &= 0x3FFFFF00
+    vals = torch.empty((n, 4), dtype=torch.int32, device=cuda)
+    vals[:, 0] = keys; vals[:, 1] = torch.arange(n, dtype=torch.int32, device=cuda)
+    vals[:, 2] = 7; vals[:, 3] = -keys
+    gh.sort_by_key(keys, vals, 0, 30)
+    assert bool((keys[1:] >= keys[:-1]).all())
+    assert torch.equal(vals[:, 0], keys) and torch.equal(vals[:, 3], -keys)
+    same = keys[1:] == keys[:-1]
+    assert bool((vals[1:, 1][same] > vals[:-1, 1][same]).all())       # equal keys keep input order
+    assert int(vals[:, 1].to(torch.int64).sum()) == n * (n - 1) // 2
