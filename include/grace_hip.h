@@ -148,7 +148,10 @@ grace_status grace_morton_keys63_points_d3(const void* d_points, size_t n, int i
  *      Keys ascending, equal keys keep their input order; values (value_bytes per element,
  *      a multiple of 4: 4/16/28/32/36 are the reference's payloads) are permuted in place.
  *      d_values may be NULL (keys only).  d_perm (optional, n uint32) receives the source
- *      index of every output element. ------------------------------------------------- */
+ *      index of every output element.  Asynchronous on `stream`, no host round trip; inputs
+ *      of 2^18 elements or more also use the context's internal side stream, forked from
+ *      and joined to `stream` by events (bucket sort with a device-gated fallback, see
+ *      csrc/sort.hip). ---------------------------------------------------------------- */
 grace_status grace_sort_pairs_u32(uint32_t* d_keys, void* d_values, size_t n, int value_bytes,
                                   int begin_bit, int end_bit, uint32_t* d_perm,
                                   grace_stream stream);

@@ -463,3 +463,46 @@ def test_bucket_sort_full_size_properties(gh, cuda):
     same = keys[1:] == keys[:-1]
     assert bool((vals[1:, 1][same] > vals[:-1, 1][same]).all())       # equal keys keep input order
     assert int(vals[:, 1].to(torch.int64).sum()) == n * (n - 1) // 2
+
+
+def test_bucket_sort_two_contexts_two_threads_and_context_teardown(gh, cuda):
+    """The bucket sort's fallback runs on the context's side stream: two threads with a context
+    and a stream each sort concurrently (one of them with overflowing buckets, so that its gated
+    index sort really runs beside the other's bucket kernels); leaving the `with` destroys the
+    contexts, side streams included."""
+    n = 500_003
+    rng = np.random.default_rng(11)
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(cuda)
+            r = np.random.default_rng(100 + k)
+            with gh.Context():
+                stream = torch.cuda.Stream(device=cuda)
+                with torch.cuda.stream(stream):
+                    for it in range(5):
+                        keys = r.integers(0, 1 << 30, n, dtype=np.uint32)
+                        if k == 1 and it % 2 == 0:
+                            keys[: n // 2] = (keys[: n // 2] & np.uint32(0xFFFF)) | np.uint32(0x2AA << 20)
+                        vals = r.integers(0, 1 << 31, (n, 4), dtype=np.int32)
+                        kd = torch.from_numpy(keys.view(np.int32)).to(cuda, non_blocking=False)
+                        vd = torch.from_numpy(vals).to(cuda)
+                        gh.sort_by_key(kd, vd, 0, 30)
+                        stream.synchronize()
+                        order = np.argsort(keys, kind="stable")
+                        if not (np.array_equal(kd.cpu().numpy().view(np.uint32), keys[order])
+                                and np.array_equal(vd.cpu().numpy(), vals[order])):
+                            errors.append((k, it, "differs"))
+        except Exception as e:      # noqa: BLE001 -- reported to the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    # and the default context still sorts
+    keys = rng.integers(0, 1 << 30, n, dtype=np.uint32)
+    _check_sort(gh, cuda, keys, None, 0, 30)
