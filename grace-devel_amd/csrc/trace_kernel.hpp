@@ -820,6 +820,11 @@ void trace_kernel(const TraceArgs a)
             // Lane j's candidate of cluster c: primitive 64 c + j, clamped into the range (idle
             // lanes then hold a valid candidate and the tests need no control flow).
             double4 mined_next = make_double4(0., 0., 0., 0.);   // *_D4: the candidate's double4 record
+            // (Round 3, measured and rejected: buffer loads for the candidates -- a resource based at
+            // the range's first cluster, the cluster as scalar offset, the lane as constant vector
+            // offset: no per-round address arithmetic (six vector instructions) and no clamps, the
+            // hardware's range check returning zeros for the masked lanes -- same images, frame
+            // kernel +-0, hit counts -1.7 %, 1/8 shard +2.3 %: not kept.)
             auto load_cluster = [&](const int c, float4& m4, float2& m2) {
                 const int pj = min(max((c << 6) + lane, r_lo), r_hi - 1);
                 m4 = a.A[pj];
@@ -857,7 +862,10 @@ void trace_kernel(const TraceArgs a)
                 // (Round 3, measured and rejected: two register sets taking turns with the round
                 // body instantiated twice -- no copies, but +11 % on the frame kernel; fetching only
                 // after the round has staged its survivors, into the same registers -- no copies
-                // either, +2.5 %: the loads need the whole round's lead.)
+                // either, +2.5 %: the loads need the whole round's lead; staging the survivors of
+                // several test-free rounds behind one another and running the survivor loop once
+                // per ~64 of them -- a third of the loop prologues, bit-identical images, +6 %:
+                // the rounds without a loop leave the prefetch no time.)
                 float4 mine_next;
                 float2 mineb_next = make_float2(0.f, 0.f);
                 load_cluster(cnext, mine_next, mineb_next);
@@ -886,7 +894,7 @@ void trace_kernel(const TraceArgs a)
                 else if constexpr (AX == -2) may_hit = pencil_may_hit(mine, s_pencil[wv]);
                 else may_hit = beam_may_hit(mine, beam);
                 unsigned long long rest = __builtin_amdgcn_ballot_w64(may_hit) & m_mask;
-                bool keep = may_hit & (lane >= lo_bit) & (lane < hi_bit);
+                bool keep = __builtin_amdgcn_inverse_ballot_w64(rest);   // (the scalar mask itself: no lane compares)
                 // Axis packets: if every kept candidate lies inside every ray's [0, length)
                 // along the axis -- decided per candidate with the same FMA the rays use, which
                 // is monotone in its addend -- the round's survivors skip the two range tests.
