@@ -786,6 +786,7 @@ grace_status sort_pairs_bucketed(Key* d_keys, void* d_values, size_t n, int valu
     uint32_t* bounds = Workspace::take<uint32_t>(bins + 8);
     uint32_t* ctl = bounds + bins + 2;
     *slow_flag = ctl + 1;
+    *side = nullptr;
 
     bucket_hist_kernel<Key><<<n_tiles, LS_THREADS, 0, stream>>>(d_keys, n, shift, msd_bits, counts);
     GRACE_CHECK_LAUNCH();
@@ -864,15 +865,23 @@ grace_status sort_pairs(Key* d_keys, void* d_values, size_t n, int value_bytes, 
     // context's side stream, so that their ~20 empty launches pass beside the bucket kernels
     // instead of after them).
     const uint32_t* gate = run_if;
-    const hipStream_t call_stream = stream;
+    // (joins the side stream back into the call's stream on every way out, errors included: the
+    // frame's fence is recorded on the call's stream only)
+    struct SideJoin {
+        hipStream_t call_stream = nullptr;
+        bool forked = false;
+        grace_status join() { const bool f = forked; forked = false; return f ? side_join(call_stream) : GRACE_OK; }
+        ~SideJoin() { (void)join(); }
+    } side_guard;
+    side_guard.call_stream = stream;
     int msd_bits = 0;
-    bool forked = false;
     if (!run_if && bucket_plan<Key>(n, end_bit - begin_bit, d_values ? value_bytes / 4 : 0, msd_bits)) {
         hipStream_t side = nullptr;
-        GRACE_TRY(sort_pairs_bucketed<Key>(d_keys, d_values, n, value_bytes, begin_bit, end_bit, msd_bits,
-                                           d_perm_out, stream, &gate, &side));
+        const grace_status st = sort_pairs_bucketed<Key>(d_keys, d_values, n, value_bytes, begin_bit, end_bit,
+                                                         msd_bits, d_perm_out, stream, &gate, &side);
+        side_guard.forked = side != nullptr;
+        if (st != GRACE_OK) return st;
         stream = side;
-        forked = true;
     }
 
     const uint32_t n_tiles = uint32_t((n + SORT_TILE - 1) / SORT_TILE);
@@ -905,8 +914,7 @@ grace_status sort_pairs(Key* d_keys, void* d_values, size_t n, int value_bytes, 
     }
     if (d_perm_out && i_in != d_perm_out)        // (cannot happen: see the ping-pong set-up)
         GRACE_TRY(copy_gated(i_in, d_perm_out, n * 4, gate, stream));
-    if (forked) GRACE_TRY(side_join(call_stream));
-    return GRACE_OK;
+    return side_guard.join();
 }
 
 } // namespace
