@@ -196,8 +196,17 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     constexpr bool CLASS_SPLIT = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_COUNT_D4
                                   || MODE == MODE_CUM_D4);
     if (CLASS_SPLIT) {
+        // (column densities: launched for up to 32768 waves -- see choose_split)
+        const size_t wave_budget = (MODE == MODE_CUMULATIVE) ? 32768 : 16384;
         if (ts.split > 0) split = ts.split;
-        else while (split < SUM_CLASSES && size_t(n_packets) * split < 16384) split *= 2;
+        else {
+            while (split < SUM_CLASSES && size_t(n_packets) * split < wave_budget) split *= 2;
+            // (the device picks the working waves per packet: scenes with spheres smaller than the ray
+            // spacing want four -- see lat_split below --, one-direction batches two, others one)
+            if (MODE == MODE_CUMULATIVE && split > 1 && split < ts.lat_split && ts.ray_reorder && n_rays > 64
+                && width == 64)
+                split = ts.lat_split;
+        }
     }
     if (hits_split) split = hit_split;
     a.split = split;
@@ -244,7 +253,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         GRACE_TRY(frame.begin((scene_cached ? 0 : Workspace::aligned((n_spheres + 4) * sizeof(float4))
                                                + Workspace::aligned((n_spheres + 4) * sizeof(float2))
                                                + Workspace::aligned(n_nodes * sizeof(int2))
-                                               + Workspace::aligned((2 * n_clusters + 1) * sizeof(float4))
+                                               + Workspace::aligned(cluster_record_count(n_spheres) * sizeof(float4))
                                                + (MODE == MODE_TRI ? Workspace::aligned(72 * (n_spheres + 4)) : 0))
                                    + (hits_split ? 2 * Workspace::aligned(n_rays * size_t(hit_chunks) * 4)
                                                    + Workspace::aligned(hit_packets * hit_split * sizeof(int4))
@@ -288,7 +297,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             float2* B = need_b ? Workspace::take<float2>(n_spheres + 4) : nullptr;
             double* T64 = (MODE == MODE_TRI) ? Workspace::take<double>(9 * (n_spheres + 4)) : nullptr;
             int2* node_prims = Workspace::take<int2>(n_nodes);
-            float4* C = Workspace::take<float4>(2 * n_clusters + 1);
+            float4* C = Workspace::take<float4>(cluster_record_count(n_spheres));
             GRACE_TRY(scene_fill(MODE == MODE_TRI ? 1 : D4 ? 2 : 0,
                                  D4 ? static_cast<const void*>(a.spheres_d) : a.spheres, n_spheres, a.nodes, n_nodes, a.leaves, A,
                                  fast_b ? nullptr : B, fast_b ? B : nullptr, T64, node_prims, C, stream));
@@ -310,13 +319,18 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
         // Subtrees of up to this many primitives are swept -- cluster tests, then culling rounds
         // over the surviving clusters -- rather than descended.
         // Axis-aligned packets test a cluster's box against their origin rectangle (sharp: large
-        // subtrees pay, 16384 measured best on full frames and shards alike); pencil packets test it
+        // subtrees pay; 16384 measured best in round 2); pencil packets test it
         // against the bundle's side planes, general packets its circumscribed sphere.
         // (re-measured after the pencil cluster test became a box-against-side-planes test: sphere
         // scenes now prefer 8192 there too -- config 2 column densities 1.74 -> 1.46 ms, hit counts
         // 1.54 -> 1.19, config 3 0.94 -> 0.87 --; triangles, culled through bounding spheres, keep 512:
         // 5.3 / 4.6 / 2.8 ms for the three cameras against 6.9 / 5.8 / 3.0 at 8192)
-        const int auto_treelet = (MODE == MODE_TRI) ? 512 : 8192, auto_treelet_axis = 16384;
+        // (round 3, after the test-free 16-byte survivor rounds made the sweeps cheaper relative to
+        // the walk: axis-aligned packets prefer 32768 -- 1024^2 frame 2.82 -> 2.78 ms, its 1/2, 1/4,
+        // 1/8 shards 1.53 -> 1.46, 0.84 -> 0.80, 0.51 -> 0.47 ms (their split waves each repeat the
+        // walk); 65536 the same, 131072 worse; clustered scenes +3 %.  Pencil / general packets stay
+        // at 8192: config 2 1.47 / 1.50 / 1.50 ms at 8192 / 16384 / 32768, config 3 0.87 / 0.83 / 0.86.)
+        const int auto_treelet = (MODE == MODE_TRI) ? 512 : 8192, auto_treelet_axis = 32768;
 #ifdef GRACE_PACKET_STATS
         a.treelet = ts.treelet < 0 ? auto_treelet : ts.treelet;
         a.treelet_axis = ts.treelet < 0 ? auto_treelet_axis : ts.treelet;
@@ -332,6 +346,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
             constexpr bool lat_mode = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_HITS);
             uint32_t* lat_flag = lat_mode ? ext + 13 : nullptr;
             int* split_dev = dev_split ? reinterpret_cast<int*>(ext + 12) : nullptr;
+            const int split_flags = (MODE == MODE_CUMULATIVE) ? SPLIT_WIDE_BUDGET : 0;
             if (rays_cached) {
                 RayOrder& ro = ts.rays;
                 if (rays_use != USE_TRUST) {
@@ -343,12 +358,12 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
                 // cached order: only this call's device-side choices remain
                 if (lat_flag || split_dev) {
                     GRACE_TRY(launch_choose_variants(ro.ext, int(n_rays), a.C + 2 * n_clusters, lat_flag,
-                                                     n_packets, split, split_dev, stream));
+                                                     n_packets, split | split_flags, split_dev, stream));
                 }
                 a.perm = ro.perm;
             } else {
                 GRACE_TRY(ray_order(a.rays, n_rays, ext, keys, perm, a.C + 2 * n_clusters, lat_flag, n_packets,
-                                    split, split_dev, stream));
+                                    split | split_flags, split_dev, stream));
                 a.perm = perm;
             }
             if (lat_mode) a.lat_dev = reinterpret_cast<const int*>(ext + 13);
@@ -359,6 +374,7 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     a.n_nodes = int(n_nodes);
     a.status = ts.status;
     a.n_prims = int(n_spheres);
+    a.group_shift = group_shift(n_spheres);
     a.chunk_shift = hit_chunk_shift;
     a.n_chunks = hit_chunks;
     a.chunk_counts = nullptr;

@@ -91,9 +91,11 @@ __global__ __launch_bounds__(1024) void ray_extents_kernel(const float* __restri
 // rays all share one direction (orthographic shards) has light packets, for which every extra
 // wave repeats the upper-tree walk and the cluster tests.  ext12 = the ray
 // extents of the coherence pass (order-preserving uints: minima then maxima of d, o).
-__device__ int choose_split(const uint32_t* __restrict__ ext12, int n_packets, int launched, bool lattice)
+__device__ int choose_split(const uint32_t* __restrict__ ext12, int n_packets, int launched_arg, bool lattice)
 {
     const bool one_direction = ext12[0] == ext12[6] && ext12[1] == ext12[7] && ext12[2] == ext12[8];
+    const int launched = launched_arg & 0xFF;
+    const int budget = (launched_arg & SPLIT_WIDE_BUDGET) ? 32768 : 16384;
     int k = launched;
     // (a scene with spheres smaller than the ray spacing has packets of very unequal weight: it
     // keeps every launched wave -- see lat_split in launch_trace)
@@ -101,9 +103,18 @@ __device__ int choose_split(const uint32_t* __restrict__ ext12, int n_packets, i
         // Measured on 1/8 ... 1/1 shards of the 1024^2 frame (2048 ... 16384 packets): best K =
         // 4, 2, 2, 1.  The split kernels run 8 waves per SIMD: 8192 waves fill the chip once;
         // from 6144 packets on a second wave per packet still pays (16384 waves).
+        // Round 3, after the walk was replaced by the flat group passes (the duplicated part of
+        // a split packet got cheaper): column densities are faster with two waves per packet up
+        // to the full frame -- 16384 packets: 2.65 ms at K = 1, 2.56 at K = 2, 2.75 at K = 4;
+        // hit counts are not (1.83 / 1.87 / 2.17): their budget stays at 16384 waves.
         k = 1;
         while (k < launched && n_packets * k < 8192) k *= 2;
-        if (k < launched && n_packets >= 6144 && n_packets * k < 16384) k *= 2;
+        if (k < launched && n_packets >= 6144 && n_packets * k * 2 <= budget) k *= 2;
+    } else if (!lattice) {
+        // incoherent batches: the smallest K that puts 16384 waves in flight (the launch may be
+        // sized for more: column densities, see launch_trace)
+        k = 1;
+        while (k < launched && n_packets * k < 16384) k *= 2;
     }
     return k;
 }

@@ -725,13 +725,99 @@ void trace_kernel(const TraceArgs a)
         }
     };
 
-    push(*a.root, ~0ull);
+    // Axis-aligned packets of the hit-count / column-density traces do not walk the tree: the
+    // primitives are Morton-sorted, so GROUPS of 2^group_shift consecutive ones (4096 up to 16.7 M
+    // primitives; <= 4096 groups) are compact cells, and their boxes -- the unions of their
+    // clusters' boxes, written by the pre-pass behind the cluster records -- are tested 64 at a
+    // time, lane j <-> group g + j, against the packet's origin rectangle and its extent along
+    // the axis.  Every surviving group is swept like a subtree the walk would have stopped at
+    // (cluster tests, then culling rounds), in ascending order.  What the walk cost -- ~100 node
+    // visits per packet, each a dependent load, repeated by every wave of a split packet -- is
+    // replaced by n / 2^18 independent, coalesced passes (39 at 10^7 primitives).  Conservative
+    // like the walk and the cluster tests: a group is dropped only if no ray of the packet can
+    // hit any member, so the per-ray hit sets, and with them every sum, are unchanged.
+    constexpr bool FLAT_OK = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_COUNT_D4
+                              || MODE == MODE_CUM_D4);
+    const bool flat = FLAT_OK && axis >= 0;
+    const float4* const group_boxes = a.C + 2 * ((size_t(a.n_prims) + 63) >> 6) + 1;
+    const int n_groups = FLAT_OK ? int((size_t(a.n_prims) + (size_t(1) << a.group_shift) - 1) >> a.group_shift) : 0;
+    unsigned long long group_mask = 0ull;   // surviving groups of the current pass, not yet swept
+    int group_next = 0;                     // first group of the next pass
+    // All passes are made up front, their loads in flight together (made one by one between the
+    // sweeps, each pass exposed its load latency: 39 of them per wave at 10^7 primitives); the
+    // survivor masks wait in LDS.
+    __shared__ unsigned long long s_group_mask[FLAT_OK ? TRACE_BLOCK / 64 : 1][FLAT_OK ? 64 : 1];
+    if (flat) {
+        const int d1 = axis == 0 ? 1 : 0, d2 = axis == 2 ? 1 : 2;
+        const float flat_lo1 = d1 == 0 ? beam.olo[0] : beam.olo[1], flat_hi1 = d1 == 0 ? beam.ohi[0] : beam.ohi[1];
+        const float flat_lo2 = d2 == 1 ? beam.olo[1] : beam.olo[2], flat_hi2 = d2 == 1 ? beam.ohi[1] : beam.ohi[2];
+        // the packet's extent along the axis: every ray's segment [o, o + d len], d = +-1
+        const float oa = axis == 0 ? ox : axis == 1 ? oy : oz;
+        const float da = axis == 0 ? dx : axis == 1 ? dy : dz;
+        const float ea = oa + da * len;
+        const float flat_alo = wave_min(fminf(oa, ea));
+        const float flat_ahi = wave_max(fmaxf(oa, ea));
+        const int wvg = threadIdx.x >> 6;
+        auto group_test = [&](const float4 glo, const float4 ghi, const int g0) {
+            const float l1 = axis == 0 ? glo.y : glo.x, h1 = axis == 0 ? ghi.y : ghi.x;
+            const float l2 = axis == 2 ? glo.y : glo.z, h2 = axis == 2 ? ghi.y : ghi.z;
+            const float la = axis == 0 ? glo.x : axis == 1 ? glo.y : glo.z;
+            const float ha = axis == 0 ? ghi.x : axis == 1 ? ghi.y : ghi.z;
+            // (negated forms: a NaN bound keeps the group)
+            const bool may = !(l1 > flat_hi1) && !(h1 < flat_lo1) && !(l2 > flat_hi2) && !(h2 < flat_lo2)
+                && !(la > flat_ahi) && !(ha < flat_alo);
+            const int n_g = n_groups - g0;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(may)
+                & (n_g >= 64 ? ~0ull : n_g <= 0 ? 0ull : ((1ull << n_g) - 1ull));
+            if (lane == 0) s_group_mask[wvg][g0 >> 6] = m;
+        };
+        for (int g0 = 0; g0 < n_groups; g0 += 256) {
+            // four passes' boxes fetched before the first test (the last group's box pads the tail)
+            float4 lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int gj = min(g0 + 64 * k + lane, n_groups - 1);
+                lo[k] = group_boxes[2 * size_t(gj)];
+                hi[k] = group_boxes[2 * size_t(gj) + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (g0 + 64 * k < n_groups) group_test(lo[k], hi[k], g0 + 64 * k);
+        }
+    } else {
+        push(*a.root, ~0ull);
+    }
     unsigned long long st_walk = 0, st_cluster = 0, st_cull = 0, st_surv = 0, st_rounds = 0, st_nsurv = 0;
     const unsigned long long st_begin = STAMP_NOW();
     (void)st_walk; (void)st_cluster; (void)st_cull; (void)st_surv; (void)st_rounds; (void)st_nsurv; (void)st_begin;
 
-    while (sp >= 0) {
+    for (;;) {
         const unsigned long long st_t0 = STAMP_NOW(); (void)st_t0;
+        int sweep_first = 0, sweep_count = 0;
+        bool sweep = false;
+        if (flat) {
+            while (group_mask == 0ull && group_next < n_groups) {
+                group_mask = s_group_mask[threadIdx.x >> 6][group_next >> 6];
+                group_mask = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(group_mask))))
+                    | ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(group_mask >> 32)))) << 32);
+                group_next += 64;
+            }
+            if (group_mask == 0ull) break;
+            const int g = group_next - 64 + __builtin_ctzll(group_mask);
+            group_mask &= group_mask - 1ull;
+            sweep_first = g << a.group_shift;
+            sweep_count = min(1 << a.group_shift, a.n_prims - sweep_first);
+            // A wave of a split packet skips groups none of whose granules it owns.
+            if (SPLIT) {
+                bool mine = false;
+                for (int gr = sweep_first >> GRANULE_SHIFT; gr <= (sweep_first + sweep_count - 1) >> GRANULE_SHIFT
+                         && gr < (sweep_first >> GRANULE_SHIFT) + SUM_CLASSES; ++gr)
+                    mine = mine || owns_granule(gr);
+                if (!mine) continue;
+            }
+            sweep = true;
+        } else {
+        if (sp < 0) break;
         int idx;
         unsigned long long alive_mask = ~0ull;
         if (sp < 64) {
@@ -748,8 +834,6 @@ void trace_kernel(const TraceArgs a)
         --sp;
         const bool alive = (alive_mask >> lane) & 1ull;
 
-        int sweep_first = 0, sweep_count = 0;
-        bool sweep = false;
         if (idx < a.n_nodes) {
             const float4* np = a.nodes + 4 * size_t(idx);
             // Node and span are fetched together (one scalar-load round trip).
@@ -795,6 +879,7 @@ void trace_kernel(const TraceArgs a)
             if (MODE == MODE_STATS && alive) { ++st_leaves; st_tested += uint32_t(lf.y); }
 #endif
         }
+        } // tree walk
         STAMP_ADD(st_walk, st_t0);
         if (sweep) {
             const int2 leaf = make_int2(sweep_first, sweep_count);

@@ -152,6 +152,39 @@ __global__ __launch_bounds__(256) void cluster_boxes_kernel(const float4* __rest
     publish_r2_min(wave_r2_min, C + 2 * n_clusters);
 }
 
+// Group boxes: the union of the boxes of 2^(shift - 6) consecutive clusters, one wave per group
+// (fminf / fmaxf like the cluster boxes: a NaN member is left out, as it is there).
+__global__ __launch_bounds__(256) void group_boxes_kernel(const float4* __restrict__ C, size_t n_clusters,
+                                                          int per_group, size_t n_groups,
+                                                          float4* __restrict__ G,
+                                                          const uint32_t* __restrict__ run_if)
+{
+    if (run_if && *run_if == 0u) return;
+    const int lane = threadIdx.x & 63;
+    for (size_t g = blockIdx.x * size_t(blockDim.x / 64) + (threadIdx.x >> 6); g < n_groups;
+         g += size_t(gridDim.x) * (blockDim.x / 64)) {
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        const size_t c0 = g * size_t(per_group);
+        for (size_t c = c0 + lane; c < c0 + per_group && c < n_clusters; c += 64) {
+            const float4 l = C[2 * c], h = C[2 * c + 1];
+            lo[0] = fminf(lo[0], l.x); lo[1] = fminf(lo[1], l.y); lo[2] = fminf(lo[2], l.z);
+            hi[0] = fmaxf(hi[0], h.x); hi[1] = fmaxf(hi[1], h.y); hi[2] = fmaxf(hi[2], h.z);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+            }
+        }
+        if (lane == 0) {
+            G[2 * g] = make_float4(lo[0], lo[1], lo[2], 0.f);
+            G[2 * g + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
+    }
+}
+
 // ---- triangle primitives (tests/profile_trace_triangle) -----------------------------------
 // Pre-pass: a bounding sphere per triangle (for the beam culling: a ray that meets the
 // triangle passes within r of the centre; r^2 is inflated by 2^-10 against fp32 rounding) and
@@ -255,7 +288,7 @@ grace_status scene_cache_alloc(TraceState& ts, const SceneKey& key)
     if (st == GRACE_OK && !tri) st = alloc(reinterpret_cast<void**>(&sc.B50), (n_prims + 4) * sizeof(float2));
     if (st == GRACE_OK && tri) st = alloc(reinterpret_cast<void**>(&sc.T64), 72 * (n_prims + 4));
     if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.node_prims), key.n_nodes * sizeof(int2));
-    if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.C), (2 * ((n_prims + 63) / 64) + 1) * sizeof(float4));
+    if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.C), cluster_record_count(n_prims) * sizeof(float4));
     if (st == GRACE_OK) st = alloc(reinterpret_cast<void**>(&sc.ctl), sizeof(CacheCtl));
     if (st != GRACE_OK) { (void)scene_free_buffers(sc); return st; }
     sc.key = key;
@@ -287,6 +320,12 @@ grace_status scene_fill(int kind, const void* prims, size_t n_prims, const float
     }
     if (kind != 0) {
         cluster_boxes_kernel<<<stream_grid((n_prims + 63) / 64, 4), 256, 0, stream>>>(A, n_prims, C, run_if);
+        GRACE_CHECK_LAUNCH();
+    }
+    {
+        const size_t n_clusters = (n_prims + 63) / 64, n_groups = group_count(n_prims);
+        group_boxes_kernel<<<stream_grid(n_groups, 4), 256, 0, stream>>>(
+            C, n_clusters, 1 << (group_shift(n_prims) - 6), n_groups, C + 2 * n_clusters + 1, run_if);
         GRACE_CHECK_LAUNCH();
     }
     return GRACE_OK;

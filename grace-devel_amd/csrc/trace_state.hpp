@@ -11,6 +11,31 @@ namespace grace_hip {
 
 constexpr int TRACE_BLOCK = 256;
 constexpr int N_TABLE = 51;
+// Flag on the `launched` argument of the device-side split choice: column densities let a second
+// wave per packet work up to 32768 waves (hit counts: 16384).
+constexpr int SPLIT_WIDE_BUDGET = 0x100;
+
+// Cluster records C of a scene of n primitives (float4 units): {lo, hi} per cluster of 64
+// consecutive primitives, one tail record (the scene's smallest r^2 and the node_prims flag), then
+// {lo, hi} per GROUP of 2^group_shift(n) consecutive primitives -- the union of its clusters'
+// boxes; at most 4096 groups, of 4096 primitives each up to 16.7 M primitives.  Axis-aligned
+// packets of the hit-count / column-density traces test the groups' boxes, 64 per lane-parallel
+// pass, instead of walking the tree down to subtrees of that size (trace_kernel.hpp).
+inline int group_shift(size_t n_prims)
+{
+    int s = 12;
+    while (((n_prims + (size_t(1) << s) - 1) >> s) > 4096) ++s;
+    return s;
+}
+inline size_t group_count(size_t n_prims)
+{
+    const int s = group_shift(n_prims);
+    return (n_prims + (size_t(1) << s) - 1) >> s;
+}
+inline size_t cluster_record_count(size_t n_prims)
+{
+    return 2 * ((n_prims + 63) / 64) + 1 + 2 * group_count(n_prims);
+}
 constexpr int MAX_HIT_CHUNKS = 256; // chunk ranges of the split per-hit trace
 constexpr int SUM_CLASSES = 8;   // summation classes (leaves of the pairwise sum tree)
 constexpr int GRANULE_SHIFT = 10; // 1024 consecutive primitives share a class
@@ -32,6 +57,7 @@ struct TraceArgs {
     int treelet_axis;       // the same for axis-aligned packets (whose cluster test is much sharper)
     const float4* A;        // pre-pass: {x, y, z, h*h}, padded by 4 entries
     const float2* B;        // pre-pass: {1/h, (1/h)^2}, padded by 4 entries
+    int group_shift;        // primitives per group box = 2^group_shift (see cluster_record_count)
     const float4* C;        // pre-pass: per CLUSTER (64 consecutive primitives) {lo.xyz, -}, {hi.xyz, -}:
                             // the box of the member spheres, slightly inflated (cluster_boxes_kernel)
     const double* T64;      // MODE_TRI pre-pass: {v, e1, e2} widened to fp64, 9 per triangle

@@ -32,6 +32,7 @@ for frac_clump, n_clumps in ((0.0,0),(0.5,200),(0.9,50)):
     rays,_=gh.orthogonal_rays_z(1024,lo,hi,device=dev); R=len(rays)
     hc=torch.empty(R,dtype=torch.int32,device=dev); cu=torch.empty(R,dtype=torch.float32,device=dev)
     gh.trace_prepare(s,tree)
+    if os.environ.get('TREELET'): gh.set_treelet_size(int(os.environ['TREELET']))
     t0=timeit(lambda: gh.trace_hitcounts_sph(rays,s,tree,hc)); hits=hc.double().sum().item()
     t1=timeit(lambda: gh.trace_cumulative_sph(rays,s,tree,cu))
     print("lattice",gh.last_lattice())
