@@ -380,9 +380,10 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_rays * args.steps / elapsed / 1e6
         # Dominant kernel: trace_kernel<cumulative>.  One launch per rank per step.
-        # MODE_CUMULATIVE, fast integral; a rank with fewer than 16384 packets of 64 rays runs the
-        # class-split instantiation (several waves per packet, csrc/trace.hip)
-        split_kernel = (per + 63) // 64 < 16384
+        # MODE_CUMULATIVE, fast integral; a rank with fewer than 32768 packets of 64 rays runs the
+        # class-split instantiation (two or more waves per packet, csrc/trace.hip: the full
+        # 1024^2 frame runs two)
+        split_kernel = (per + 63) // 64 < 32768
         # (last parameter: the lattice instantiation, for scenes with spheres smaller than the ray
         # spacing -- not this one)
         kernel_name = "trace_kernel<1, %s, true, false>" % ("true" if split_kernel else "false")
@@ -393,11 +394,11 @@ def main():
         alg_per_launch = alg_bytes_total / world
         img = image[:frame_rays]   # frame 0
         # Compulsory bytes: everything the launch must read at least once --
-        # the pre-pass records of all particles (16 + 8 B), every node (64 B + 8 B span) and
-        # leaf (16 B), the cluster boxes (32 B per 64 particles), this rank's rays (28 B) --
-        # plus 4 B written per ray.
-        compulsory = (24 * n + n // 2 + 72 * (tree.n_leaves - 1) + 16 * tree.n_leaves
-                      + 32 * (n_rays // world))
+        # the pre-pass records of all particles (16 + 8 B), the cluster boxes (32 B per 64
+        # particles) and group boxes (32 B per 4096), this rank's rays (28 B + 4 B of order) --
+        # plus 4 B written per ray.  (Axis-aligned packets no longer read the tree's nodes and
+        # leaves -- 72 B and 16 B each, counted here up to round 3's flat group passes.)
+        compulsory = (24 * n + n // 2 + n // 128 + 36 * (n_rays // world))
         roof = {
             "bound": "valu", "kernel": kernel_name, "unit": "G wave-instr/s",
             "peak": VALU_PEAK_GINST, "achieved": None, "frac": None, "traffic": None,
