@@ -738,7 +738,7 @@ void trace_kernel(const TraceArgs a)
     // hit any member, so the per-ray hit sets, and with them every sum, are unchanged.
     constexpr bool FLAT_OK = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_COUNT_D4
                               || MODE == MODE_CUM_D4);
-    const bool flat = FLAT_OK && axis >= 0;
+    const bool flat = FLAT_OK;
     const float4* const group_boxes = a.C + 2 * ((size_t(a.n_prims) + 63) >> 6) + 1;
     const int n_groups = FLAT_OK ? int((size_t(a.n_prims) + (size_t(1) << a.group_shift) - 1) >> a.group_shift) : 0;
     unsigned long long group_mask = 0ull;   // surviving groups of the current pass, not yet swept
@@ -747,7 +747,31 @@ void trace_kernel(const TraceArgs a)
     // sweeps, each pass exposed its load latency: 39 of them per wave at 10^7 primitives); the
     // survivor masks wait in LDS.
     __shared__ unsigned long long s_group_mask[FLAT_OK ? TRACE_BLOCK / 64 : 1][FLAT_OK ? 64 : 1];
-    if (flat) {
+    if (flat && axis < 0) {
+        // pencil / general packets: the cluster test of their kind on the group boxes
+        const int wvg = threadIdx.x >> 6;
+        for (int g0 = 0; g0 < n_groups; g0 += 128) {
+            float4 lo[2], hi[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int gj = min(g0 + 64 * k + lane, n_groups - 1);
+                lo[k] = group_boxes[2 * size_t(gj)];
+                hi[k] = group_boxes[2 * size_t(gj) + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int gk = g0 + 64 * k;
+                if (gk < n_groups) {
+                    const bool may = is_pencil ? cluster_may_hit<-2>(lo[k], hi[k], beam, &s_pencil[wvg])
+                                               : cluster_may_hit<-1>(lo[k], hi[k], beam, &s_pencil[wvg]);
+                    const int n_g = n_groups - gk;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(may)
+                        & (n_g >= 64 ? ~0ull : ((1ull << n_g) - 1ull));
+                    if (lane == 0) s_group_mask[wvg][gk >> 6] = m;
+                }
+            }
+        }
+    } else if (flat) {
         const int d1 = axis == 0 ? 1 : 0, d2 = axis == 2 ? 1 : 2;
         const float flat_lo1 = d1 == 0 ? beam.olo[0] : beam.olo[1], flat_hi1 = d1 == 0 ? beam.ohi[0] : beam.ohi[1];
         const float flat_lo2 = d2 == 1 ? beam.olo[1] : beam.olo[2], flat_hi2 = d2 == 1 ? beam.ohi[1] : beam.ohi[2];
