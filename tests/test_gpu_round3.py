@@ -506,3 +506,59 @@ def test_bucket_sort_two_contexts_two_threads_and_context_teardown(gh, cuda):
     # and the default context still sorts
     keys = rng.integers(0, 1 << 30, n, dtype=np.uint32)
     _check_sort(gh, cuda, keys, None, 0, 30)
+
+
+# ---- flat group passes (csrc/trace_kernel.hpp): hit counts and column densities test the boxes of
+# ---- groups of 4096 Morton-consecutive primitives instead of walking the tree
+
+@pytest.mark.parametrize("n", [33, 4095, 4096, 4097, 8191, 12289, 70001])
+@pytest.mark.parametrize("kind", ["axis+", "axis-", "pencil", "general"])
+def test_group_passes_equal_brute_force(gh, oracle, cuda, n, kind):
+    """Scene sizes around the group boundaries (one group, exactly one, one primitive into the
+    next, a short last group, many groups), every packet kind that takes the group passes, rays
+    that stop short of / start inside the box (the extent test along the axis), and every split of
+    the packets: hit counts equal the brute-force loop, column densities the oracle's sums."""
+    rng = np.random.default_rng(n)
+    s = oracle.random_real4(n, (0, 0, 0, 0.01), (1, 1, 1, 0.06))
+    d = torch.from_numpy(s).to(cuda)
+    tree = gh.Tree(n, 32 if n > 64 else 2, device=cuda)
+    gh.build_tree(d, tree, (0, 0, 0), (1, 1, 1))
+    ss = d.cpu().numpy()                      # sorted in place by the build
+    side = 40
+    u, v = np.meshgrid((np.arange(side) + 0.5) / side, (np.arange(side) + 0.5) / side)
+    rays = np.zeros((side * side, 7), np.float32)
+    if kind.startswith("axis"):
+        sense = 1.0 if kind == "axis+" else -1.0
+        rays[:, 2] = sense
+        rays[:, 3] = u.ravel(); rays[:, 4] = v.ravel()
+        start = rng.uniform(-0.2, 0.7, len(rays)).astype(np.float32)
+        rays[:, 5] = start if sense > 0 else (1.0 - start)
+        rays[:, 6] = rng.uniform(0.05, 1.5, len(rays)).astype(np.float32)
+    else:
+        dirs = rng.standard_normal((len(rays), 3)); dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+        rays[:, :3] = dirs.astype(np.float32)
+        if kind == "pencil":
+            rays[:, 3:6] = np.float32(0.5)
+        else:
+            rays[:, 3:6] = rng.uniform(0.2, 0.8, (len(rays), 3)).astype(np.float32)
+        rays[:, 6] = rng.uniform(0.1, 1.2, len(rays)).astype(np.float32)
+    dr = torch.from_numpy(rays).to(cuda)
+    want_c = oracle.brute_hitcounts(rays, ss)
+    ref32, ref64 = oracle.brute_cumulative(rays, ss)
+    max_term = float(oracle.kernel_table()[0]) / 0.01 ** 2
+    from conftest import check_column_densities
+    try:
+        for split in (-1, 1, 4, 8):
+            gh.set_packet_split(split)
+            for exact in (False, True):
+                gh.set_exact_integrals(exact)
+                hc = torch.empty(len(rays), dtype=torch.int32, device=cuda)
+                cu = torch.empty(len(rays), dtype=torch.float32, device=cuda)
+                gh.trace_hitcounts_sph(dr, d, tree, hc)
+                gh.trace_cumulative_sph(dr, d, tree, cu)
+                gh.trace_status()
+                assert np.array_equal(hc.cpu().numpy(), want_c), (split, exact)
+                check_column_densities(cu.cpu().numpy(), ref32, ref64, "exact" if exact else "fast",
+                                       max_term=max_term)
+    finally:
+        gh.set_packet_split(-1); gh.set_exact_integrals(False)
