@@ -33,10 +33,15 @@
 //     whose tiles are the same and whose tile order suits the dispatcher better, and for
 //     general batches); results do not depend on it; a batch traced repeatedly can have its
 //     order prepared once (grace_trace_prepare_rays);
-//   * treelet sweep with a cluster level: a node whose subtree holds <= T primitives (contiguous
-//     indices; T = 16384 for axis-aligned packets, 8192 otherwise, 512 for triangles) is not
-//     descended: one box per 64 consecutive primitives (a pre-pass) is tested first, lane j
-//     for cluster j, and only the surviving clusters go through culling rounds of 64;
+//   * hit counts and column densities do not walk the tree: primitives are Morton-sorted, so
+//     groups of 4096 consecutive ones are compact cells; a packet tests all group boxes up
+//     front, 64 per lane-parallel pass (boxes behind the cluster records, masks kept in LDS),
+//     and sweeps the surviving groups in ascending order (trace_kernel.hpp);
+//   * the per-hit traces, triangles and the stats walk descend the tree to subtrees of <= T
+//     primitives (contiguous indices; T = 8192, 512 for triangles) and sweep those;
+//   * a sweep (of a group or a subtree) has a cluster level: one box per 64 consecutive
+//     primitives (a pre-pass) is tested first, lane j for cluster j, and only the surviving
+//     clusters go through culling rounds of 64;
 //   * scenes with spheres smaller than the ray spacing (dense cores of clustered SPH data) run
 //     a separate instantiation (LAT), selected by a device flag: an exact cull against the
 //     packet's origin lattice, and four waves per packet for big batches (their packets are
