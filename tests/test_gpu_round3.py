@@ -562,3 +562,33 @@ def test_group_passes_equal_brute_force(gh, oracle, cuda, n, kind):
                                        max_term=max_term)
     finally:
         gh.set_packet_split(-1); gh.set_exact_integrals(False)
+
+
+def test_group_passes_fall_back_to_the_walk_for_wide_packets(gh, oracle, cuda):
+    """A packet that keeps more than 256 groups (here: two packets' worth of isotropic rays from
+    one origin, and from two origins, through 1.5 M small spheres = 367 groups) walks the tree
+    instead: the same counts and sums as the brute-force loop either way."""
+    n = 1_500_000
+    s = oracle.random_real4(n, (0, 0, 0, 0.002), (1, 1, 1, 0.012))
+    d = torch.from_numpy(s).to(cuda)
+    tree = gh.Tree(n, 32, device=cuda)
+    gh.build_tree(d, tree, (0, 0, 0), (1, 1, 1))
+    ss = d.cpu().numpy()
+    rng = np.random.default_rng(3)
+    from conftest import check_column_densities
+    for origins in ([(0.5, 0.5, 0.5)], [(0.3, 0.3, 0.3), (0.7, 0.6, 0.5)]):
+        R = 128
+        dirs = rng.standard_normal((R, 3)); dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+        rays = np.zeros((R, 7), np.float32)
+        rays[:, :3] = dirs.astype(np.float32)
+        rays[:, 3:6] = np.array(origins, np.float32)[np.arange(R) % len(origins)]
+        rays[:, 6] = 2.0
+        dr = torch.from_numpy(rays).to(cuda)
+        hc = torch.empty(R, dtype=torch.int32, device=cuda)
+        cu = torch.empty(R, dtype=torch.float32, device=cuda)
+        gh.trace_hitcounts_sph(dr, d, tree, hc)
+        gh.trace_cumulative_sph(dr, d, tree, cu)
+        gh.trace_status()
+        assert np.array_equal(hc.cpu().numpy(), oracle.brute_hitcounts(rays, ss))
+        ref32, ref64 = oracle.brute_cumulative(rays, ss)
+        check_column_densities(cu.cpu().numpy(), ref32, ref64, "fast")
