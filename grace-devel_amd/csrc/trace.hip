@@ -201,8 +201,9 @@ grace_status launch_trace(TraceArgs a, size_t n_rays, size_t n_spheres, size_t n
     constexpr bool CLASS_SPLIT = (MODE == MODE_COUNT || MODE == MODE_CUMULATIVE || MODE == MODE_COUNT_D4
                                   || MODE == MODE_CUM_D4);
     if (CLASS_SPLIT) {
-        // (column densities: launched for up to 32768 waves -- see choose_split)
-        const size_t wave_budget = (MODE == MODE_CUMULATIVE) ? 32768 : 16384;
+        // (column densities: a batch of exactly 16384 packets -- the 1024^2 frame -- still gets a
+        // second wave per packet, 32768 waves; see choose_split.  Larger batches run one.)
+        const size_t wave_budget = (MODE == MODE_CUMULATIVE) ? 16385 : 16384;
         if (ts.split > 0) split = ts.split;
         else {
             while (split < SUM_CLASSES && size_t(n_packets) * split < wave_budget) split *= 2;
