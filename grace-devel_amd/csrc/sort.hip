@@ -602,9 +602,61 @@ __global__ __launch_bounds__(LS_THREADS, 4) void bucket_finish_kernel(
         }
     }
     __syncthreads();
-    for (int done = 0; done < low_bits; done += 8) {
+    // Keys with more than 24 bits below the bucket digit (63-bit Morton keys: 51): the passes cover
+    // the TOP 24 of them; what is left below decides only between records that agree on everything
+    // above -- a handful of pairs among 10^7 spread keys -- and is settled by a stable insertion
+    // sort of those runs, one thread per run.  A bucket with a run of more than TIE_RUN_MAX records
+    // (keys that differ in their low bits only) is sorted over all its bits instead: the passes are
+    // stable, so starting from the present order is as good as starting from the input's.
+    constexpr int TIE_RUN_MAX = 8;
+    const int tie_bits = low_bits > 24 ? low_bits - 24 : 0;
+    for (int done = tie_bits; done < low_bits; done += 8) {
         const int bits = low_bits - done < 8 ? low_bits - done : 8;
         lds_radix_pass<Key, TILE>(s_key, s_src, cnt, begin_bit + done, bits, s_cnt, s_start, s_wtot);
+    }
+    if (tie_bits > 0) {
+        __shared__ uint32_t s_long_run;
+        if (threadIdx.x == 0) s_long_run = 0;
+        __syncthreads();
+        const int above = begin_bit + tie_bits;                         // first bit the passes covered
+        const Key tie_mask = (Key(1) << tie_bits) - Key(1);
+        // (bits above the bucket digit are not part of the key: the digit's own bits and everything
+        // the passes covered are compared; records of one bucket agree on the digit anyway)
+        const int top = begin_bit + low_bits;
+        auto prefix = [&](const Key k) { return (k >> above) & ((Key(1) << (top - above)) - Key(1)); };
+        for (uint32_t p = threadIdx.x; p < cnt; p += LS_THREADS) {
+            const Key mine = prefix(s_key[p]);
+            const bool head = (p == 0 || prefix(s_key[p - 1]) != mine) && p + 1 < cnt && prefix(s_key[p + 1]) == mine;
+            if (head) {
+                uint32_t e = p + 1;
+                while (e < cnt && e - p <= uint32_t(TIE_RUN_MAX) && prefix(s_key[e]) == mine) ++e;
+                if (e - p > uint32_t(TIE_RUN_MAX)) {
+                    s_long_run = 1u;            // (benign race: every writer writes 1)
+                } else {
+                    // stable insertion sort of [p, e) by the low bits (this thread owns the run)
+                    for (uint32_t i = p + 1; i < e; ++i) {
+                        const Key ki = s_key[i];
+                        const uint16_t si = s_src[i];
+                        const Key li = (ki >> begin_bit) & tie_mask;
+                        uint32_t j = i;
+                        while (j > p && ((s_key[j - 1] >> begin_bit) & tie_mask) > li) {
+                            s_key[j] = s_key[j - 1];
+                            s_src[j] = s_src[j - 1];
+                            --j;
+                        }
+                        s_key[j] = ki;
+                        s_src[j] = si;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_long_run) {
+            for (int done = 0; done < low_bits; done += 8) {
+                const int bits = low_bits - done < 8 ? low_bits - done : 8;
+                lds_radix_pass<Key, TILE>(s_key, s_src, cnt, begin_bit + done, bits, s_cnt, s_start, s_wtot);
+            }
+        }
     }
     Payload<W> pay[ROUNDS];
     if constexpr (W > 0) {
@@ -715,7 +767,7 @@ bool bucket_plan(size_t n, int bits, int words, int& msd_bits)
     while (m < LS_MAX_MSD_BITS && (n >> m) * 10 > TILE * 6) ++m;
     if ((n >> m) * 4 > TILE * 3) return false;      // mean bucket above 75 % of a workgroup: too many would overflow
     if (m > bits) return false;                     // fewer key values than buckets needed
-    if (bits - m > 24) return false;                // > 3 LDS passes per bucket (63-bit keys): measured slower
+    if (bits - m > 24 && sizeof(Key) < 8) return false;   // (cannot happen: 32-bit keys leave <= 31 - m bits)
     msd_bits = m;
     return true;
 }

@@ -592,3 +592,20 @@ def test_group_passes_fall_back_to_the_walk_for_wide_packets(gh, oracle, cuda):
         assert np.array_equal(hc.cpu().numpy(), oracle.brute_hitcounts(rays, ss))
         ref32, ref64 = oracle.brute_cumulative(rays, ss)
         check_column_densities(cu.cpu().numpy(), ref32, ref64, "fast")
+
+
+@pytest.mark.parametrize("repeat", [1, 3, 8, 9, 40])
+@pytest.mark.parametrize("words", [0, 4])
+def test_bucket_sort_long_keys_tie_runs(gh, cuda, repeat, words):
+    """63-bit keys: the bucket kernel sorts the top 24 bits below the bucket digit by LDS passes and
+    settles the rest inside runs of records that agree on everything above -- `repeat` records per
+    36-bit prefix, differing (or not) in the 27 bits below: single records, short runs (insertion
+    sort), runs beyond 8 (the bucket is re-sorted over all its bits)."""
+    n = 400_000 // repeat * repeat
+    rng = np.random.default_rng(repeat + 10 * words)
+    prefixes = rng.integers(0, 1 << 36, n // repeat, dtype=np.uint64)
+    keys = (np.repeat(prefixes, repeat) << np.uint64(27)) | rng.integers(0, 1 << 27, n, dtype=np.uint64)
+    keys[::5] &= ~np.uint64(0x7FFFFFF)                       # some fully equal keys too: stability
+    keys = keys[rng.permutation(n)]
+    vals = rng.integers(0, 1 << 31, (n, words), dtype=np.int32) if words else None
+    _check_sort(gh, cuda, keys, vals, 0, 63, want_perm=(words == 0))
