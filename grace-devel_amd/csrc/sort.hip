@@ -199,9 +199,11 @@ constexpr int LS_THREADS = 512;
 constexpr int LS_WAVES = LS_THREADS / 64;
 constexpr int LS_MAX_MSD_BITS = 12;
 
-template <typename Key> struct LocalSort;
-template <> struct LocalSort<uint32_t> { static constexpr int TILE = 8192; };
-template <> struct LocalSort<uint64_t> { static constexpr int TILE = 4096; };
+// Records per tile / per bucket capacity: 8192 for 32-bit keys with payloads of up to 16 bytes;
+// 4096 for 64-bit keys (LDS) and for the wide payloads (28, 32, 36 bytes: the payload of a
+// thread's records rides in registers, 8 records x 9 words at most).
+constexpr int local_tile(int key_bytes, int words) { return (key_bytes == 8 || words > 4) ? 4096 : 8192; }
+template <typename Key, int W> struct LocalSort { static constexpr int TILE = local_tile(int(sizeof(Key)), W); };
 
 // One stable counting pass in LDS over cnt <= TILE (key, src) records: reordered in place by the
 // digit key[shift, shift + bits), bits <= 8.  Wave w owns a contiguous, equal share of the
@@ -308,10 +310,9 @@ __device__ __forceinline__ void lds_radix_pass(Key* __restrict__ s_key, uint16_t
 
 template <typename Key>
 __global__ __launch_bounds__(LS_THREADS) void bucket_hist_kernel(const Key* __restrict__ keys, size_t n,
-                                                                 int shift, int msd_bits,
+                                                                 int shift, int msd_bits, int TILE,
                                                                  uint32_t* __restrict__ counts)   // [tile][bin]
 {
-    constexpr int TILE = LocalSort<Key>::TILE;
     __shared__ uint32_t s_hist[1 << LS_MAX_MSD_BITS];
     const uint32_t bins = 1u << msd_bits;
     for (uint32_t k = threadIdx.x; k < bins; k += LS_THREADS) s_hist[k] = 0;
@@ -445,9 +446,12 @@ template <int W>
 __device__ __forceinline__ Payload<W> load_payload(const uint32_t* __restrict__ src)
 {
     Payload<W> v;
-    if constexpr (W == 4) {
-        const uint4 q = *reinterpret_cast<const uint4*>(src);
-        v.w[0] = q.x; v.w[1] = q.y; v.w[2] = q.z; v.w[3] = q.w;
+    if constexpr (W == 4 || W == 8) {
+#pragma unroll
+        for (int h = 0; h < W / 4; ++h) {
+            const uint4 q = reinterpret_cast<const uint4*>(src)[h];
+            v.w[4 * h + 0] = q.x; v.w[4 * h + 1] = q.y; v.w[4 * h + 2] = q.z; v.w[4 * h + 3] = q.w;
+        }
     } else if constexpr (W == 2) {
         const uint2 q = *reinterpret_cast<const uint2*>(src);
         v.w[0] = q.x; v.w[1] = q.y;
@@ -461,8 +465,10 @@ __device__ __forceinline__ Payload<W> load_payload(const uint32_t* __restrict__ 
 template <int W>
 __device__ __forceinline__ void store_payload(uint32_t* __restrict__ dst, const Payload<W>& v)
 {
-    if constexpr (W == 4) {
-        *reinterpret_cast<uint4*>(dst) = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+    if constexpr (W == 4 || W == 8) {
+#pragma unroll
+        for (int h = 0; h < W / 4; ++h)
+            reinterpret_cast<uint4*>(dst)[h] = make_uint4(v.w[4 * h], v.w[4 * h + 1], v.w[4 * h + 2], v.w[4 * h + 3]);
     } else if constexpr (W == 2) {
         *reinterpret_cast<uint2*>(dst) = make_uint2(v.w[0], v.w[1]);
     } else {
@@ -488,8 +494,9 @@ __global__ __launch_bounds__(LS_THREADS, 4) void bucket_scatter_kernel(
     uint32_t* __restrict__ vals_out, uint32_t* __restrict__ idx_out, const uint32_t* __restrict__ run_if)
 {
     if (*run_if == 0u) return;
-    constexpr int TILE = LocalSort<Key>::TILE;
+    constexpr int TILE = LocalSort<Key, W>::TILE;
     constexpr int ROUNDS = TILE / LS_THREADS;
+    constexpr int CHUNK = W > 4 ? ((LS_CHUNK * 4) / W) / 64 * 64 : LS_CHUNK;   // slots of the 16 KB window
     __shared__ Key s_key[TILE];
     __shared__ uint16_t s_src[TILE];
     __shared__ uint16_t s_cnt[LS_WAVES * 256];
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(LS_THREADS, 4) void bucket_scatter_kernel(
     __shared__ uint32_t s_wtot[4];
     __shared__ __attribute__((aligned(16))) uint32_t s_chunk[LS_CHUNK * 4];   // (also: TILE uint16 of scratch)
     extern __shared__ uint32_t s_gbase[];    // [1 << msd_bits]: global slot of the tile's slot 0 of the run
-    static_assert(LS_CHUNK * 4 * 4 >= TILE * 2, "the inverse map borrows the chunk window");
+    static_assert(LS_CHUNK * 4 * 4 >= TILE * 2 && CHUNK >= 64, "the inverse map borrows the chunk window");
 
     const uint32_t tile = xcd_tile(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
@@ -560,14 +567,14 @@ __global__ __launch_bounds__(LS_THREADS, 4) void bucket_scatter_kernel(
             const uint32_t p = threadIdx.x + k * LS_THREADS;
             slot_of[k] = p < cnt ? s_src[p] : 0xFFFFFFFFu;
         }
-        for (uint32_t c0 = 0; c0 < cnt; c0 += LS_CHUNK) {
+        for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
 #pragma unroll
             for (int k = 0; k < ROUNDS; ++k) {
                 const uint32_t rel = slot_of[k] - c0;
-                if (rel < uint32_t(LS_CHUNK)) store_payload<W>(s_chunk + rel * W, pay[k]);
+                if (rel < uint32_t(CHUNK)) store_payload<W>(s_chunk + rel * W, pay[k]);
             }
             __syncthreads();
-            for (uint32_t j = threadIdx.x; j < uint32_t(LS_CHUNK) && c0 + j < cnt; j += LS_THREADS)
+            for (uint32_t j = threadIdx.x; j < uint32_t(CHUNK) && c0 + j < cnt; j += LS_THREADS)
                 store_payload<W>(vals_out + size_t(s_dst[c0 + j]) * W, load_payload<W>(s_chunk + j * W));
             __syncthreads();
         }
@@ -582,8 +589,9 @@ __global__ __launch_bounds__(LS_THREADS, 4) void bucket_finish_kernel(
     const uint32_t* __restrict__ run_if)
 {
     if (*run_if == 0u) return;
-    constexpr int TILE = LocalSort<Key>::TILE;
+    constexpr int TILE = LocalSort<Key, W>::TILE;
     constexpr int ROUNDS = TILE / LS_THREADS;
+    constexpr int CHUNK = W > 4 ? ((LS_CHUNK * 4) / W) / 64 * 64 : LS_CHUNK;   // slots of the 16 KB window
     __shared__ Key s_key[TILE];
     __shared__ uint16_t s_src[TILE];
     __shared__ uint16_t s_cnt[LS_WAVES * 256];
@@ -679,14 +687,14 @@ __global__ __launch_bounds__(LS_THREADS, 4) void bucket_finish_kernel(
             const uint32_t p = threadIdx.x + k * LS_THREADS;
             slot_of[k] = p < cnt ? s_src[p] : 0xFFFFFFFFu;
         }
-        for (uint32_t c0 = 0; c0 < cnt; c0 += LS_CHUNK) {
+        for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
 #pragma unroll
             for (int k = 0; k < ROUNDS; ++k) {
                 const uint32_t rel = slot_of[k] - c0;
-                if (rel < uint32_t(LS_CHUNK)) store_payload<W>(s_chunk + rel * W, pay[k]);
+                if (rel < uint32_t(CHUNK)) store_payload<W>(s_chunk + rel * W, pay[k]);
             }
             __syncthreads();
-            for (uint32_t j = threadIdx.x; j < uint32_t(LS_CHUNK) && c0 + j < cnt; j += LS_THREADS)
+            for (uint32_t j = threadIdx.x; j < uint32_t(CHUNK) && c0 + j < cnt; j += LS_THREADS)
                 store_payload<W>(vals_out + (size_t(first) + c0 + j) * W, load_payload<W>(s_chunk + j * W));
             __syncthreads();
         }
@@ -758,8 +766,8 @@ grace_status gather_payload(const void* d_in, const uint32_t* d_perm, void* d_ou
 template <typename Key>
 bool bucket_plan(size_t n, int bits, int words, int& msd_bits)
 {
-    if (words > 4) return false;                    // (the payload rides in registers: 16 bytes at most)
-    constexpr size_t TILE = LocalSort<Key>::TILE;
+    if (words > 9) return false;
+    const size_t TILE = size_t(local_tile(int(sizeof(Key)), words));
     // (measured, 30-bit keys + 16 B: equal at 2^17 elements, 0.127 against 0.164 ms at 2^18, 0.131 /
     // 0.190 at 2^20, 0.40 / 0.61 at 10^7; 16-bit keys -- two index passes -- are a draw at any size)
     if (n < (size_t(1) << 18) || bits <= 16) return false;
@@ -776,7 +784,7 @@ size_t sort_ws_bytes_impl(size_t n, int key_bytes, int value_bytes)
 {
     const size_t n_tiles = (n + SORT_TILE - 1) / SORT_TILE;
     const size_t n_counts = size_t(RADIX) * n_tiles;
-    const size_t tile_b = key_bytes == 8 ? LocalSort<uint64_t>::TILE : LocalSort<uint32_t>::TILE;
+    const size_t tile_b = 4096;      // (the smallest tile of the bucket sort: most tiles)
     const size_t n_counts_b = (size_t(1) << LS_MAX_MSD_BITS) * ((n + tile_b - 1) / tile_b);
     return 2 * Workspace::aligned(n * size_t(key_bytes)) + 3 * Workspace::aligned(n * 4)
         + Workspace::aligned(n * size_t(value_bytes)) + Workspace::aligned(n_counts * 4) + Workspace::aligned(scan_ws_count(n_counts) * 4)
@@ -823,8 +831,8 @@ grace_status sort_pairs_bucketed(Key* d_keys, void* d_values, size_t n, int valu
                                  int end_bit, int msd_bits, uint32_t* d_perm_out, hipStream_t stream,
                                  const uint32_t** slow_flag, hipStream_t* side)
 {
-    constexpr size_t TILE = LocalSort<Key>::TILE;
     const int words = d_values ? value_bytes / 4 : 0;
+    const size_t TILE = size_t(local_tile(int(sizeof(Key)), words));
     const uint32_t bins = 1u << msd_bits;
     const uint32_t n_tiles = uint32_t((n + TILE - 1) / TILE);
     const size_t n_counts = size_t(bins) * n_tiles;
@@ -840,7 +848,7 @@ grace_status sort_pairs_bucketed(Key* d_keys, void* d_values, size_t n, int valu
     *slow_flag = ctl + 1;
     *side = nullptr;
 
-    bucket_hist_kernel<Key><<<n_tiles, LS_THREADS, 0, stream>>>(d_keys, n, shift, msd_bits, counts);
+    bucket_hist_kernel<Key><<<n_tiles, LS_THREADS, 0, stream>>>(d_keys, n, shift, msd_bits, int(TILE), counts);
     GRACE_CHECK_LAUNCH();
     const dim3 col_grid((bins + BUCKET_COL_BLOCK - 1) / BUCKET_COL_BLOCK, BUCKET_SEGS);
     bucket_colsum_kernel<<<col_grid, BUCKET_COL_BLOCK, 0, stream>>>(counts, bins, n_tiles, seg_sum);
@@ -863,7 +871,10 @@ grace_status sort_pairs_bucketed(Key* d_keys, void* d_values, size_t n, int valu
     case 1: GRACE_BUCKET_LAUNCH(1); break;
     case 2: GRACE_BUCKET_LAUNCH(2); break;
     case 3: GRACE_BUCKET_LAUNCH(3); break;
-    default: GRACE_BUCKET_LAUNCH(4); break;
+    case 4: GRACE_BUCKET_LAUNCH(4); break;
+    case 7: GRACE_BUCKET_LAUNCH(7); break;
+    case 8: GRACE_BUCKET_LAUNCH(8); break;
+    default: GRACE_BUCKET_LAUNCH(9); break;
     }
 #undef GRACE_BUCKET_LAUNCH
     GRACE_CHECK_LAUNCH();

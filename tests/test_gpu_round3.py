@@ -394,7 +394,7 @@ def _check_sort(gh, cuda, keys, vals, begin, end, want_perm=True):
         assert np.array_equal(perm.cpu().numpy().view(np.uint32), order.astype(np.uint32))
 
 
-@pytest.mark.parametrize("words", [0, 1, 2, 3, 4, 7, 8])
+@pytest.mark.parametrize("words", [0, 1, 2, 3, 4, 7, 8, 9])
 @pytest.mark.parametrize("n", [262144, 262145, 300001, 1 << 20])
 def test_bucket_sort_uniform_keys(gh, cuda, n, words):
     rng = np.random.default_rng(n + words)
