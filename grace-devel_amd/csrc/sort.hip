@@ -502,7 +502,7 @@ __global__ __launch_bounds__(LS_THREADS, 4) void bucket_scatter_kernel(
     __shared__ uint16_t s_cnt[LS_WAVES * 256];
     __shared__ uint32_t s_start[256];
     __shared__ uint32_t s_wtot[4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[LS_CHUNK * 4];   // (also: TILE uint16 of scratch)
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[W > 0 ? LS_CHUNK * 4 : 4];   // (also: TILE uint16 of scratch)
     extern __shared__ uint32_t s_gbase[];    // [1 << msd_bits]: global slot of the tile's slot 0 of the run
     static_assert(LS_CHUNK * 4 * 4 >= TILE * 2 && CHUNK >= 64, "the inverse map borrows the chunk window");
 
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(LS_THREADS, 4) void bucket_finish_kernel(
     __shared__ uint16_t s_cnt[LS_WAVES * 256];
     __shared__ uint32_t s_start[256];
     __shared__ uint32_t s_wtot[4];
-    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[LS_CHUNK * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_chunk[W > 0 ? LS_CHUNK * 4 : 4];
     const uint32_t first = bounds[blockIdx.x];
     const uint32_t cnt = bounds[blockIdx.x + 1] - first;
     if (cnt == 0 || cnt > uint32_t(TILE)) return;     // (cnt > TILE cannot happen when *run_if is set)
