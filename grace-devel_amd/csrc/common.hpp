@@ -70,6 +70,14 @@ struct Context {
     // forked from and joined to the call's stream by events, see side_fork / side_join
     hipStream_t side_stream = nullptr;
     hipEvent_t side_fork_ev = nullptr, side_join_ev = nullptr;
+    // Bucket sort: did the last large sort on this context overflow a bucket?  A word of pinned,
+    // device-mapped host memory that the sort's flag kernel writes (no copy, no synchronisation);
+    // the NEXT large sort reads it as a hint -- keys that overflowed once (clustered snapshots)
+    // mostly do again, and the attempt costs ~0.06 ms -- and goes straight to the index sort,
+    // retrying the bucket sort every 8th time.  Only ever a choice between two correct paths.
+    volatile uint32_t* sort_overflow_host = nullptr;
+    uint32_t* sort_overflow_dev = nullptr;      // the device's view of the same word
+    uint32_t sort_hint_skips = 0;
     // traversal state, owned by the trace translation units
     TraceState* trace = nullptr;
 };
@@ -78,6 +86,8 @@ struct Context {
 grace_status side_fork(hipStream_t stream, hipStream_t* side);
 // ... and `stream` ordered after everything enqueued on the side stream so far.
 grace_status side_join(hipStream_t stream);
+// The frame context's overflow hint word (allocated on first use; null if pinned memory is refused).
+uint32_t* sort_overflow_word(Context** ctx_out);
 
 // The calling thread's context: the one it made current, else the current device's default
 // context.  Fails if the thread's explicit context belongs to another device than the current one.

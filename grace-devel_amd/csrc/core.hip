@@ -81,7 +81,32 @@ static grace_status context_clear(Context& c)
     }
     c.side_stream = nullptr;
     c.side_fork_ev = c.side_join_ev = nullptr;
+    if (c.sort_overflow_host) (void)hipHostFree(const_cast<uint32_t*>(c.sort_overflow_host));
+    c.sort_overflow_host = nullptr;
+    c.sort_overflow_dev = nullptr;
+    c.sort_hint_skips = 0;
     return GRACE_OK;
+}
+
+uint32_t* sort_overflow_word(Context** ctx_out)
+{
+    Context* c = Workspace::frame_context();
+    if (ctx_out) *ctx_out = c;
+    if (!c) return nullptr;
+    if (!c->sort_overflow_host) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(h);
+            return nullptr;
+        }
+        *static_cast<uint32_t*>(h) = 0u;
+        c->sort_overflow_host = static_cast<volatile uint32_t*>(h);
+        c->sort_overflow_dev = static_cast<uint32_t*>(d);
+    }
+    return c->sort_overflow_dev;
 }
 
 grace_status side_fork(hipStream_t stream, hipStream_t* side)

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_scatter_kernel(
 // no host round trip), so that case costs the index sort plus the histogram of the top bits.
 // HBM traffic per 30-bit key with a 16-byte payload: 4 + (20 + 20) + (20 + 20) = 84 B.
 
+bool g_overflow_hint_on = true;     // grace_sort_set_overflow_hint
+
 constexpr int LS_THREADS = 512;
 constexpr int LS_WAVES = LS_THREADS / 64;
 constexpr int LS_MAX_MSD_BITS = 12;
@@ -355,7 +357,8 @@ __global__ __launch_bounds__(BUCKET_COL_BLOCK) void bucket_colsum_kernel(const u
 __global__ __launch_bounds__(1024) void bucket_bases_kernel(uint32_t* __restrict__ seg_sum, uint32_t n,
                                                             uint32_t bins, uint32_t cap,
                                                             uint32_t* __restrict__ bounds,
-                                                            uint32_t* __restrict__ ctl)
+                                                            uint32_t* __restrict__ ctl,
+                                                            uint32_t* __restrict__ overflow_hint)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_over;
@@ -411,7 +414,10 @@ __global__ __launch_bounds__(1024) void bucket_bases_kernel(uint32_t* __restrict
     if (threadIdx.x == 0) bounds[bins] = n;
     if (over) atomicOr(&s_over, 1u);
     __syncthreads();
-    if (threadIdx.x == 0) { ctl[0] = s_over ? 0u : 1u; ctl[1] = s_over ? 1u : 0u; }
+    if (threadIdx.x == 0) {
+        ctl[0] = s_over ? 0u : 1u; ctl[1] = s_over ? 1u : 0u;
+        if (overflow_hint) *overflow_hint = s_over ? 1u : 0u;      // (pinned host word: see Context)
+    }
 }
 
 __global__ __launch_bounds__(BUCKET_COL_BLOCK) void bucket_colscan_kernel(uint32_t* __restrict__ counts, uint32_t bins,
@@ -853,7 +859,8 @@ grace_status sort_pairs_bucketed(Key* d_keys, void* d_values, size_t n, int valu
     const dim3 col_grid((bins + BUCKET_COL_BLOCK - 1) / BUCKET_COL_BLOCK, BUCKET_SEGS);
     bucket_colsum_kernel<<<col_grid, BUCKET_COL_BLOCK, 0, stream>>>(counts, bins, n_tiles, seg_sum);
     GRACE_CHECK_LAUNCH();
-    bucket_bases_kernel<<<1, 1024, 0, stream>>>(seg_sum, uint32_t(n), bins, uint32_t(TILE), bounds, ctl);
+    bucket_bases_kernel<<<1, 1024, 0, stream>>>(seg_sum, uint32_t(n), bins, uint32_t(TILE), bounds, ctl,
+                                                sort_overflow_word(nullptr));
     GRACE_CHECK_LAUNCH();
     bucket_colscan_kernel<<<col_grid, BUCKET_COL_BLOCK, 0, stream>>>(counts, bins, n_tiles, seg_sum);
     GRACE_CHECK_LAUNCH();
@@ -938,7 +945,17 @@ grace_status sort_pairs(Key* d_keys, void* d_values, size_t n, int value_bytes, 
     } side_guard;
     side_guard.call_stream = stream;
     int msd_bits = 0;
-    if (!run_if && bucket_plan<Key>(n, end_bit - begin_bit, d_values ? value_bytes / 4 : 0, msd_bits)) {
+    bool try_buckets = !run_if && bucket_plan<Key>(n, end_bit - begin_bit, d_values ? value_bytes / 4 : 0, msd_bits);
+    if (try_buckets) {
+        // the hint of the last large sort on this context (see Context::sort_overflow_host)
+        Context* ctx = nullptr;
+        (void)sort_overflow_word(&ctx);
+        if (g_overflow_hint_on && ctx && ctx->sort_overflow_host && *ctx->sort_overflow_host != 0u) {
+            if (++ctx->sort_hint_skips < 8) try_buckets = false;
+            else ctx->sort_hint_skips = 0;               // every 8th time: look again
+        }
+    }
+    if (try_buckets) {
         hipStream_t side = nullptr;
         const grace_status st = sort_pairs_bucketed<Key>(d_keys, d_values, n, value_bytes, begin_bit, end_bit,
                                                          msd_bits, d_perm_out, stream, &gate, &side);
@@ -1015,6 +1032,12 @@ grace_status grace_sort_pairs_u32(uint32_t* d_keys, void* d_values, size_t n, in
 {
     return sort_pairs<uint32_t>(d_keys, d_values, n, value_bytes, begin_bit, end_bit, d_perm,
                                 as_stream(stream));
+}
+
+grace_status grace_sort_set_overflow_hint(int enabled)
+{
+    g_overflow_hint_on = enabled != 0;
+    return GRACE_OK;
 }
 
 grace_status grace_sort_pairs_u64(uint64_t* d_keys, void* d_values, size_t n, int value_bytes,

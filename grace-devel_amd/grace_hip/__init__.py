@@ -160,6 +160,11 @@ def sort_by_key(keys, values=None, begin_bit=0, end_bit=None, want_perm=False):
     return perm
 
 
+def set_sort_overflow_hint(enabled):
+    """grace_sort_set_overflow_hint: remember per context that the last large sort overflowed."""
+    _check(_lib.grace_sort_set_overflow_hint(C.c_int(1 if enabled else 0)))
+
+
 def morton_keys30_sort_sph(spheres, bot=None, top=None):
     """build_sph.cuh:41-58: keys + stable sort of the spheres by key, in place."""
     keys = torch.empty(len(spheres), dtype=torch.int32, device=spheres.device)

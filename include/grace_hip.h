@@ -158,6 +158,12 @@ grace_status grace_sort_pairs_u32(uint32_t* d_keys, void* d_values, size_t n, in
 grace_status grace_sort_pairs_u64(uint64_t* d_keys, void* d_values, size_t n, int value_bytes,
                                   int begin_bit, int end_bit, uint32_t* d_perm,
                                   grace_stream stream);
+/* Large sorts try the bucket sort first and fall back to the index sort on the device when a bucket
+ * overflows (clustered keys).  The library remembers per context whether the last large sort
+ * overflowed -- a word of pinned host memory written by the sort's own kernel, never waited for --
+ * and then goes straight to the index sort, looking again every 8th time.  0 switches the memory
+ * off (every large sort tries the buckets); the choice is between two paths with identical results. */
+grace_status grace_sort_set_overflow_hint(int enabled);
 
 /* ---- deltas: grace::compute_deltas (include/grace/cuda/kernels/albvh.cuh:33-47,949-978)
  *      with DeltaEuclidean / DeltaSurfaceArea / DeltaXOR

@@ -609,3 +609,26 @@ def test_bucket_sort_long_keys_tie_runs(gh, cuda, repeat, words):
     keys = keys[rng.permutation(n)]
     vals = rng.integers(0, 1 << 31, (n, words), dtype=np.int32) if words else None
     _check_sort(gh, cuda, keys, vals, 0, 63, want_perm=(words == 0))
+
+
+def test_bucket_sort_overflow_hint(gh, cuda):
+    """With the hint on, a context whose large sort overflowed goes straight to the index sort for the
+    next large sorts and looks again at the 8th; results are the same on either path."""
+    n = 400_000
+    rng = np.random.default_rng(9)
+    uniform = rng.integers(0, 1 << 30, n, dtype=np.uint32)
+    clustered = uniform.copy()
+    clustered[: n // 2] = (clustered[: n // 2] & np.uint32(0xFFFF)) | np.uint32(0x155 << 20)
+    vals = rng.integers(0, 1 << 31, (n, 4), dtype=np.int32)
+    gh.set_sort_overflow_hint(True)
+    try:
+        with gh.Context():
+            _check_sort(gh, cuda, uniform, vals, 0, 30)
+            _check_sort(gh, cuda, clustered, vals, 0, 30)        # overflows: hint set
+            torch.cuda.synchronize()
+            for _ in range(10):                                   # skipped 7 times, retried, cleared
+                _check_sort(gh, cuda, uniform, vals, 0, 30)
+                torch.cuda.synchronize()
+            _check_sort(gh, cuda, clustered, vals, 0, 30)
+    finally:
+        gh.set_sort_overflow_hint(False)
